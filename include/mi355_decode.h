@@ -1,0 +1,164 @@
+/*
+ * mi355_decode.h -- C ABI of libmi355_decode.so, the MI355X (gfx950) batched-decode engine.
+ *
+ * The reference (misanthropic-ai/mlx_parallm) has NO FFI / plugin interface: its boundary is
+ * the Python API in mlx_parallm/utils.py and everything below it is the third-party MLX
+ * runtime.  This ABI sits where MLX sits today; each entry point names the reference
+ * interface it replaces (file:line in the reference checkout).  The Python side that binds
+ * it is mlx_parallm_amd/_lib.py (ctypes); INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - return 0 = OK, <0 = error class; message via mi_last_error() (thread local).
+ *       MI_ERR_INVALID  (-1)  -> Python ValueError
+ *       MI_ERR_NOTFOUND (-2)  -> Python FileNotFoundError / KeyError
+ *       MI_ERR_UNSUPPORTED(-3)-> Python NotImplementedError
+ *       MI_ERR_RUNTIME  (-4)  -> Python RuntimeError (HIP failure, out of memory, no device)
+ *   - the caller owns every host buffer it passes, for the duration of the call only;
+ *     the library owns all device memory behind its handles; every *_create has a *_destroy.
+ *   - one mi_engine per device; calls on one engine are NOT re-entrant (the reference is
+ *     single-flight too: utils.py:1345, server/main.py:1076-1107).  Different engines may be
+ *     driven from different host threads / processes concurrently.
+ *   - there is NO CPU backend: without a HIP device mi_engine_create fails with
+ *     MI_ERR_RUNTIME.
+ */
+#ifndef MI355_DECODE_H
+#define MI355_DECODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_INVALID (-1)
+#define MI_ERR_NOTFOUND (-2)
+#define MI_ERR_UNSUPPORTED (-3)
+#define MI_ERR_RUNTIME (-4)
+
+/* element types of tensors handed to mi_engine_set_tensor / activation + KV storage */
+#define MI_F32 0
+#define MI_BF16 1
+#define MI_F16 2
+#define MI_U32 3 /* MLX-packed quantised weights: 32/bits codes per word, little-endian */
+
+#define MI_ARCH_LLAMA 0 /* mlx_parallm/models/llama.py (also model_type "mistral": utils.py:33-36) */
+#define MI_ARCH_QWEN3 1 /* mlx_parallm/models/qwen3.py: + per-head q_norm/k_norm (qwen3.py:65-70) */
+
+/* KV-cache element type selector for mi_kv_create */
+#define MI_KV_MODEL (-1) /* BatchedKVCache semantics: KV in the model dtype (models/base.py:66-85) */
+/* MI_F32 on a 16-bit model = PagedKVCache semantics: float32 KV and everything after the
+ * layer-0 attention promoted to float32 (models/base.py:104-117). */
+
+typedef struct mi_engine mi_engine; /* opaque; replaces the nn.Module returned by utils.load (utils.py:711-747) */
+typedef struct mi_kv mi_kv;         /* opaque; replaces List[PagedKVCache] from _KVPool.get (utils.py:199-223) */
+
+/* ModelArgs (llama.py:15-46 / mlx-lm qwen3 ModelArgs) + config.json["quantization"] (utils.py:679-690) */
+typedef struct mi_model_desc {
+  int32_t arch;              /* MI_ARCH_* */
+  int32_t hidden_size;
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;
+  int32_t intermediate_size;
+  int32_t vocab_size;
+  float rms_norm_eps;
+  float rope_theta;
+  float rope_scale;          /* 1/factor for linear rope_scaling, else 1 (llama.py:69-76) */
+  int32_t tie_word_embeddings;
+  int32_t act_dtype;         /* MI_F32 | MI_BF16 | MI_F16: dtype of the weights (dense) or scales (quantised) */
+  int32_t quant_bits;        /* 0 = no quantised tensors; else 4 or 8 */
+  int32_t quant_group_size;  /* 64 (32 / 128 also accepted) */
+  int32_t max_positions;     /* RoPE table length = largest KV capacity a mi_kv may have */
+} mi_model_desc;
+
+/* arguments of the `sample` closure (utils.py:345-364) + top_p_sampling (sample_utils.py:3-38) */
+typedef struct mi_sample_params {
+  float temperature;         /* 0 -> greedy argmax (utils.py:352-353) */
+  float top_p;               /* 0<top_p<1 -> nucleus (utils.py:355-356), else plain categorical */
+  int32_t n_logit_bias;      /* logit_bias dict (utils.py:346-349) */
+  const int32_t* logit_bias_ids;
+  const float* logit_bias_values;
+  const float* uniforms;     /* [B] caller-supplied U[0,1) noise, or NULL -> library Philox stream */
+  uint64_t seed;             /* Philox key when uniforms == NULL */
+  int32_t top_logprobs;      /* 0..MI_MAX_TOP_LOGPROBS: also return the k most likely tokens */
+} mi_sample_params;
+
+#define MI_MAX_TOP_LOGPROBS 20
+
+/* ---- engine life cycle: replaces utils.load_model (utils.py:630-708) ------------------- */
+int mi_engine_create(const mi_model_desc* desc, int device, mi_engine** out);
+void mi_engine_destroy(mi_engine* e);
+
+/* One call per checkpoint tensor, named as in the safetensors file (e.g.
+ * "model.layers.3.self_attn.q_proj.weight" / ".scales" / ".biases", "model.norm.weight",
+ * "lm_head.weight"); replaces model.load_weights (utils.py:693-702).  `data` is a host
+ * pointer (on_device = 0) or a device pointer on the engine's device (on_device = 1, e.g. a
+ * torch tensor that was just filled by an RCCL broadcast); the bytes are COPIED.
+ * Unknown names -> MI_ERR_NOTFOUND (the reference filters them, utils.py:693-698). */
+int mi_engine_set_tensor(mi_engine* e, const char* name, const void* data, const int64_t* shape,
+                         int ndim, int dtype, int on_device);
+
+/* LoRALinear for one projection (mlx-lm load_adapters, utils.py:742-744; file layout
+ * rl_training/lora_init.py:140-153).  proj: "self_attn.q_proj" etc.  A is (K, r), B is (r, N),
+ * row-major, dtype MI_F32/BF16/F16.  y += (scale * ((x A) B)).astype(x.dtype). */
+int mi_engine_set_lora(mi_engine* e, int layer, const char* proj, const void* A, const void* B,
+                       int rank, float scale, int dtype, int on_device);
+
+/* checks that every tensor was set, fuses q|k|v and gate|up buffers, builds RoPE tables */
+int mi_engine_finalize(mi_engine* e);
+
+/* ---- KV cache: replaces _KVPool.get / PagedKVCache (utils.py:199-223, base.py:93-150) -- */
+int mi_kv_create(mi_engine* e, int batch, int capacity_tokens, int kv_dtype, mi_kv** out);
+void mi_kv_destroy(mi_kv* kv);
+int mi_kv_reset(mi_kv* kv, int batch);               /* base.py:146-149 */
+int mi_kv_reserve(mi_kv* kv, int capacity_tokens);   /* base.py:104-117 growth, contents kept */
+int mi_kv_offsets(const mi_kv* kv, int32_t* out);    /* base.py:142-144: per-row lengths [B] */
+int mi_kv_capacity(const mi_kv* kv);
+
+/* ---- forward: replaces `model(y, cache=cache)` (utils.py:403; llama.py:243-253) --------- */
+/* tokens [B,L] row-major.  L>1 = prefill with the additive causal mask of base.py:17-40
+ * (left pads ARE attended, quirk Q1); L==1 = decode.  logits_out: NULL, or [B,V] floats of
+ * the last position (utils.py:404), or [B,L,V] if all_pos.  Synchronous. */
+int mi_forward(mi_engine* e, mi_kv* kv, const int32_t* tokens, int B, int L, float* logits_out,
+               int all_pos);
+
+/* ---- one generate_step iteration: `_step` (utils.py:401-418), synchronous -------------- */
+/* tokens_in [B,L].  Outputs (any may be NULL): tokens_out [B]; logprob_out [B] =
+ * log_softmax(logits)[b, token_b]; prob_row0_out [B] = softmax(logits)[0, token_b] (the
+ * `probs` the reference yields, quirk Q6); topk_ids/topk_logprobs [B,top_logprobs]. */
+int mi_decode_sample(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L,
+                     const mi_sample_params* sp, int32_t* tokens_out, float* logprob_out,
+                     float* prob_row0_out, int32_t* topk_ids, float* topk_logprobs);
+
+/* ---- pipelined form of the same step: the reference's one-step-ahead
+ *      mx.async_eval(next_y); mx.eval(y) (utils.py:420-427) ----------------------------- */
+/* Enqueue one step on the engine's stream and return a ticket.  tokens_in == NULL feeds the
+ * tokens sampled by the previous enqueued step (they never leave the device). */
+int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L,
+                    const mi_sample_params* sp, int64_t* ticket);
+/* Block until `ticket` has finished; copy out its results (same meaning as mi_decode_sample). */
+int mi_step_wait(mi_engine* e, int64_t ticket, int32_t* tokens_out, float* logprob_out,
+                 float* prob_row0_out, int32_t* topk_ids, float* topk_logprobs);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------- */
+/* Bracket every launch of the kernel family `name` ("gemv_gate_up", "gemv_qkv", "gemv_o",
+ * "gemv_down", "gemv_head", "attn_decode", ...; NULL or "" = off) with HIP events on the
+ * engine's own stream. */
+int mi_profile_select(mi_engine* e, const char* name);
+/* Drains the recorded events: number of launches and their summed duration in ms. */
+int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
+/* Enable/disable hipGraph replay of the decode step (default on). */
+int mi_engine_set_option(mi_engine* e, const char* key, int64_t value);
+/* Blocks until the engine's stream is idle. */
+int mi_engine_sync(mi_engine* e);
+
+const char* mi_last_error(void);
+const char* mi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_DECODE_H */

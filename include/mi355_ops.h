@@ -1,0 +1,96 @@
+/*
+ * mi355_ops.h -- kernel-level entry points of libmi355_decode.so.
+ *
+ * These expose the individual HIP kernels behind mi355_decode.h on caller-owned DEVICE
+ * buffers (e.g. torch tensors) so that each fused stage can be checked against the oracle at
+ * its own scale and timed on its own (bench.py roofline leg).  They are not needed to use the
+ * engine.  Every call runs on the HIP null stream of the current device and synchronises
+ * before returning.  Error convention as in mi355_decode.h.
+ *
+ * Reference op each one replaces (MLX call sites in the reference):
+ *   mi_op_gemv        nn.Linear / nn.QuantizedLinear (+ fused RMSNorm / residual / SwiGLU):
+ *                     llama.py:64-67,93,143,160-165,175-177,188-190,250-252; qwen3.py:37-40,63,115
+ *   mi_op_embed       nn.Embedding / QuantizedEmbedding: llama.py:212; qwen3.py:166
+ *   mi_op_rope_append q_norm/k_norm + nn.RoPE + cache.update_and_fetch:
+ *                     qwen3.py:65-70; llama.py:107-125; base.py:66-85,119-140
+ *   mi_op_attention   mx.fast.scaled_dot_product_attention + causal mask: llama.py:139-141; base.py:17-40
+ *   mi_op_sample      sample closure + top_p_sampling: utils.py:345-364; sample_utils.py:3-38
+ */
+#ifndef MI355_OPS_H
+#define MI355_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* weight kinds */
+#define MI_WK_F32 0
+#define MI_WK_BF16 1
+#define MI_WK_F16 2
+#define MI_WK_Q4_F32 3
+#define MI_WK_Q4_BF16 4
+#define MI_WK_Q4_F16 5
+#define MI_WK_Q8_F32 6
+#define MI_WK_Q8_BF16 7
+#define MI_WK_Q8_F16 8
+
+/* run-time logical rounding on top of the storage dtype */
+#define MI_RND_NONE 0
+#define MI_RND_BF16 1
+#define MI_RND_F16 2
+
+#define MI_PRO_NONE 0
+#define MI_PRO_NORM 1
+
+#define MI_EPI_STORE 0
+#define MI_EPI_STORE_F32 1
+#define MI_EPI_RESID 2
+#define MI_EPI_SWIGLU 3
+
+typedef struct mi_op_linear {
+  int32_t wk;            /* MI_WK_* */
+  int32_t N, K, group;
+  const void* w;         /* [N][K] dense, or MLX-packed [N][K*bits/32] */
+  const void* scales;    /* [N][K/group] */
+  const void* biases;
+} mi_op_linear;
+
+typedef struct mi_op_gemv_args {
+  const void* x;         /* [M][ldx] */
+  int32_t ldx, M;
+  int32_t act, rnd;      /* MI_F32/BF16/F16 storage, MI_RND_* */
+  int32_t pro;           /* MI_PRO_* */
+  int32_t epi;           /* MI_EPI_* */
+  const void* norm_w;    /* [K] */
+  float eps;
+  int32_t ldo;
+  void* out;
+  void* resid;
+  int32_t pair_offset;
+  int32_t force_generic; /* 1 = never take the MFMA path */
+} mi_op_gemv_args;
+
+typedef struct mi_op_attn_shape {
+  int32_t B, L, Hq, Hkv, D;
+  int32_t act, kv, rnd, cap;
+} mi_op_attn_shape;
+
+int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a);
+int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a);
+int mi_op_embed(const mi_op_linear* w, const int32_t* tokens, int rows, int act, int rnd, void* out);
+int mi_op_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int head_dim, float base, float scale);
+int mi_op_rope_append(const mi_op_attn_shape* s, const void* qkv, void* q_out, void* kcache, void* vcache,
+                      const int32_t* offsets, const void* q_norm_w, const void* k_norm_w, float eps,
+                      const float* cos_tab, const float* sin_tab, int max_pos);
+int mi_op_attention(const mi_op_attn_shape* s, const void* q, const void* kcache, const void* vcache,
+                    const int32_t* offsets, void* out, float scale, int nsplit, float* partial);
+int mi_op_sample(float* logits, int B, int V, float temperature, float top_p, const float* uniforms,
+                 int top_logprobs, int32_t* tokens_out, float* logprob_out, float* prob_row0_out,
+                 int32_t* topk_ids, float* topk_logprobs, float* row_stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_OPS_H */

@@ -1,0 +1,89 @@
+// common.h -- shared host/device helpers for libmi355_decode (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/mi355_decode.h"
+
+namespace mi {
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define MI_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::mi::fail(MI_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+  } while (0)
+
+#define MI_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != MI_OK) return _rc; \
+  } while (0)
+
+// ---- element types ------------------------------------------------------------------------
+using bf16 = __bf16;
+using f16 = _Float16;
+
+inline size_t dtype_size(int dt) {
+  switch (dt) {
+    case MI_F32: return 4;
+    case MI_BF16: return 2;
+    case MI_F16: return 2;
+    case MI_U32: return 4;
+  }
+  return 0;
+}
+
+// Rounding of an fp32 value to the logical activation dtype, selected at run time.  Used
+// where the storage is wider than the logical dtype (float32 KV "PagedKVCache" mode keeps
+// every activation buffer in float32 but layer 0 still rounds like the 16-bit model would).
+enum : int { RND_NONE = 0, RND_BF16 = 1, RND_F16 = 2 };
+
+__device__ __forceinline__ float round_rt(float v, int rnd) {
+  if (rnd == RND_BF16) return (float)(bf16)v;
+  if (rnd == RND_F16) return (float)(f16)v;
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// value -> storage type T with the run-time logical rounding applied first
+template <typename T>
+__device__ __forceinline__ T store_act(float v, int rnd) { return (T)round_rt(v, rnd); }
+
+// 16-byte vector of raw bits
+struct alignas(16) u128 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ float bf16lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// weight kinds for the generic kernels
+enum : int {
+  WK_F32 = 0, WK_BF16 = 1, WK_F16 = 2,
+  WK_Q4_F32 = 3, WK_Q4_BF16 = 4, WK_Q4_F16 = 5,
+  WK_Q8_F32 = 6, WK_Q8_BF16 = 7, WK_Q8_F16 = 8,
+};
+inline bool wk_is_quant(int wk) { return wk >= WK_Q4_F32; }
+inline int wk_bits(int wk) { return wk >= WK_Q8_F32 ? 8 : (wk >= WK_Q4_F32 ? 4 : 0); }
+inline int wk_scale_dtype(int wk) { return wk_is_quant(wk) ? (wk - 3) % 3 : wk; }
+
+}  // namespace mi

@@ -1,0 +1,763 @@
+// engine.hip -- host runtime behind the C ABI of include/mi355_decode.h.
+//
+// One mi_engine = one model replica on one MI355X: device-resident weights (q|k|v and gate|up
+// fused into single matrices), RoPE tables, an activation workspace, a private HIP stream and
+// a small ring of pinned result slots for the one-step-ahead pipelining of generate_step
+// (utils.py:420-427).  One mi_kv = the per-layer KV buffers of one batch, laid out
+// [layer][B][Hkv][capacity][D], plus per-row lengths that live ON THE DEVICE so that a decode
+// step needs no host data at all.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace mi {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(int code, const std::string& m) { g_err = m; return code; }
+
+int launch_gemv_v1(const LinearW& W, const GemvCall& c, hipStream_t st);
+int launch_gemv_mfma(const LinearW& W, const GemvCall& c, hipStream_t st);
+bool gemv_mfma_supported(const LinearW& W, const GemvCall& c);
+
+int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st) {
+  if (gemv_mfma_supported(W, c)) return launch_gemv_mfma(W, c, st);
+  return launch_gemv_v1(W, c, st);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+namespace {
+
+struct FusedLinear {
+  LinearW W;
+  int parts = 0;                 // bit mask of sub-tensors seen (weight / scales / biases per part)
+  int n_parts = 1;
+  int part_rows[3] = {0, 0, 0};
+  bool quant = false;
+  int dense_dtype = -1, scale_dtype = -1;
+  size_t w_bytes = 0, s_bytes = 0;
+  void* w = nullptr; void* scales = nullptr; void* biases = nullptr;
+  float* lora_a[2] = {nullptr, nullptr};
+  float* lora_b[2] = {nullptr, nullptr};
+  int seen_w[3] = {0, 0, 0}, seen_s[3] = {0, 0, 0}, seen_b[3] = {0, 0, 0};
+};
+
+struct LayerW {
+  FusedLinear qkv, o, gate_up, down;
+  void* in_norm = nullptr; void* post_norm = nullptr; void* q_norm = nullptr; void* k_norm = nullptr;
+};
+
+constexpr int NSLOT = 4;
+struct Slot {
+  hipEvent_t ev = nullptr;
+  int32_t* tokens = nullptr; float* logprob = nullptr; float* prob0 = nullptr;
+  int32_t* topk_ids = nullptr; float* topk_lp = nullptr;   // pinned host
+  int B = 0, topk = 0; int64_t ticket = -1;
+};
+
+}  // namespace
+
+struct mi_engine {
+  mi_model_desc d{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<LayerW> layers;
+  FusedLinear embed, lm_head;
+  void* final_norm = nullptr;
+  bool finalized = false;
+  float* cos_tab = nullptr; float* sin_tab = nullptr;
+  // workspace
+  size_t ws_rows = 0; size_t ws_logit_rows = 0;
+  void* h = nullptr; void* qkv = nullptr; void* q = nullptr; void* attn = nullptr; void* act = nullptr;
+  float* logits = nullptr; float* lora_t = nullptr;
+  int32_t* d_tokens = nullptr; size_t d_tokens_cap = 0;
+  int32_t* d_next = nullptr;      // tokens sampled by the last step [maxB]
+  float* d_logprob = nullptr; float* d_prob0 = nullptr; float* d_rowstats = nullptr; float* d_uniforms = nullptr;
+  int32_t* d_topk_ids = nullptr; float* d_topk_lp = nullptr;
+  int32_t* d_bias_ids = nullptr; float* d_bias_vals = nullptr;
+  int maxB = 0;
+  int max_lora_rank = 0;
+  Slot slots[NSLOT];
+  int64_t next_ticket = 0;
+  uint64_t step_counter = 0;
+  // profiling
+  std::string prof_name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  int opt_force_v1 = 0;
+};
+
+struct mi_kv {
+  mi_engine* e = nullptr;
+  int B = 0, cap = 0, dtype = MI_F32;
+  bool quirk = false;            // float32 "PagedKVCache" semantics on a 16-bit model
+  void* k = nullptr; void* v = nullptr;
+  int32_t* d_off = nullptr;
+  std::vector<int32_t> h_off;
+  float* partial = nullptr; int partial_splits = 0;
+};
+
+namespace {
+
+struct Prof {
+  mi_engine* e; bool on; hipEvent_t a = nullptr, b = nullptr;
+  Prof(mi_engine* e_, const char* name) : e(e_), on(!e_->prof_name.empty() && e_->prof_name == name) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); }
+  }
+  ~Prof() { if (on) { hipEventRecord(b, e->stream); e->prof_events.emplace_back(a, b); } }
+};
+
+int kind_of(const FusedLinear& f, int bits) {
+  if (!f.quant) return f.dense_dtype == MI_F32 ? WK_F32 : (f.dense_dtype == MI_BF16 ? WK_BF16 : WK_F16);
+  const int base = bits == 8 ? WK_Q8_F32 : WK_Q4_F32;
+  return base + (f.scale_dtype == MI_F32 ? 0 : (f.scale_dtype == MI_BF16 ? 1 : 2));
+}
+
+int copy_in(void* dst, const void* src, size_t bytes, int on_device, hipStream_t st) {
+  MI_HIP(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  MI_HIP(hipStreamSynchronize(st));
+  return MI_OK;
+}
+
+// sub-tensor `part` of a fused linear: kind 0 = weight, 1 = scales, 2 = biases
+int set_linear(mi_engine* e, FusedLinear& f, int part, int K, int kind, const void* data, const int64_t* shape,
+               int ndim, int dtype, int on_device, const std::string& name) {
+  const mi_model_desc& d = e->d;
+  if (ndim != 2) return fail(MI_ERR_INVALID, name + ": expected a 2-D tensor");
+  const int rows = f.part_rows[part];
+  int total = 0, row0 = 0;
+  for (int i = 0; i < f.n_parts; ++i) { if (i < part) row0 += f.part_rows[i]; total += f.part_rows[i]; }
+  if (shape[0] != rows) return fail(MI_ERR_INVALID, name + ": wrong number of rows");
+  if (kind == 0) {
+    const bool packed = dtype == MI_U32;
+    if (packed && d.quant_bits == 0) return fail(MI_ERR_INVALID, name + ": packed weights but desc.quant_bits == 0");
+    const int64_t cols = packed ? (int64_t)K * d.quant_bits / 32 : K;
+    if (shape[1] != cols) return fail(MI_ERR_INVALID, name + ": wrong number of columns");
+    if (!packed && dtype != d.act_dtype)
+      return fail(MI_ERR_UNSUPPORTED, name + ": dense weight dtype differs from the model dtype");
+    if (f.w != nullptr && f.quant != packed) return fail(MI_ERR_UNSUPPORTED, name + ": fused parts mix dense and quantised weights");
+    const size_t row_bytes = (size_t)cols * dtype_size(dtype);
+    if (f.w == nullptr) {
+      f.quant = packed; f.dense_dtype = packed ? -1 : dtype; f.w_bytes = row_bytes * total;
+      MI_HIP(hipMalloc(&f.w, f.w_bytes));
+    }
+    MI_TRY(copy_in((char*)f.w + (size_t)row0 * row_bytes, data, row_bytes * rows, on_device, e->stream));
+    f.seen_w[part] = 1;
+  } else {
+    if (d.quant_bits == 0) return fail(MI_ERR_INVALID, name + ": scales/biases but desc.quant_bits == 0");
+    if (K % d.quant_group_size != 0) return fail(MI_ERR_INVALID, name + ": K not divisible by the group size");
+    const int64_t cols = K / d.quant_group_size;
+    if (shape[1] != cols) return fail(MI_ERR_INVALID, name + ": wrong number of groups");
+    if (dtype != MI_F32 && dtype != MI_BF16 && dtype != MI_F16) return fail(MI_ERR_INVALID, name + ": bad dtype");
+    if (f.scale_dtype >= 0 && f.scale_dtype != dtype) return fail(MI_ERR_UNSUPPORTED, name + ": mixed scale dtypes");
+    f.scale_dtype = dtype;
+    const size_t row_bytes = (size_t)cols * dtype_size(dtype);
+    void*& dst = kind == 1 ? f.scales : f.biases;
+    if (dst == nullptr) { f.s_bytes = row_bytes * total; MI_HIP(hipMalloc(&dst, f.s_bytes)); }
+    MI_TRY(copy_in((char*)dst + (size_t)row0 * row_bytes, data, row_bytes * rows, on_device, e->stream));
+    (kind == 1 ? f.seen_s : f.seen_b)[part] = 1;
+  }
+  return MI_OK;
+}
+
+int set_vector(mi_engine* e, void*& dst, int n, const void* data, const int64_t* shape, int ndim, int dtype,
+               int on_device, const std::string& name) {
+  if (ndim != 1 || shape[0] != n) return fail(MI_ERR_INVALID, name + ": wrong shape");
+  if (dtype != e->d.act_dtype) return fail(MI_ERR_UNSUPPORTED, name + ": norm weight dtype differs from the model dtype");
+  if (dst == nullptr) MI_HIP(hipMalloc(&dst, (size_t)n * dtype_size(dtype)));
+  return copy_in(dst, data, (size_t)n * dtype_size(dtype), on_device, e->stream);
+}
+
+int finalize_linear(mi_engine* e, FusedLinear& f, int K, const std::string& name) {
+  int total = 0;
+  for (int i = 0; i < f.n_parts; ++i) {
+    total += f.part_rows[i];
+    if (!f.seen_w[i]) return fail(MI_ERR_NOTFOUND, name + ": weight not set");
+    if (f.quant && (!f.seen_s[i] || !f.seen_b[i])) return fail(MI_ERR_NOTFOUND, name + ": scales/biases not set");
+  }
+  if (f.quant && f.scale_dtype != e->d.act_dtype)
+    return fail(MI_ERR_UNSUPPORTED, name + ": scale dtype differs from the model dtype");
+  f.W.wk = kind_of(f, e->d.quant_bits);
+  f.W.w = f.w; f.W.scales = f.scales; f.W.biases = f.biases;
+  f.W.N = total; f.W.K = K; f.W.group = e->d.quant_group_size > 0 ? e->d.quant_group_size : 64;
+  return MI_OK;
+}
+
+void free_linear(FusedLinear& f) {
+  hipFree(f.w); hipFree(f.scales); hipFree(f.biases);
+  for (int i = 0; i < 2; ++i) { hipFree(f.lora_a[i]); hipFree(f.lora_b[i]); }
+}
+
+int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
+  const mi_model_desc& d = e->d;
+  if (rows > e->ws_rows) {
+    MI_HIP(hipStreamSynchronize(e->stream));
+    hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->lora_t);
+    const size_t es = 4;  // sized for float32 activations (the widest mode)
+    const size_t nqkv = (size_t)(d.num_heads + 2 * d.num_kv_heads) * d.head_dim;
+    MI_HIP(hipMalloc(&e->h, rows * d.hidden_size * es));
+    MI_HIP(hipMalloc(&e->qkv, rows * nqkv * es));
+    MI_HIP(hipMalloc(&e->q, rows * (size_t)d.num_heads * d.head_dim * es));
+    MI_HIP(hipMalloc(&e->attn, rows * (size_t)d.num_heads * d.head_dim * es));
+    MI_HIP(hipMalloc(&e->act, rows * (size_t)d.intermediate_size * es));
+    MI_HIP(hipMalloc(&e->lora_t, rows * 2 * 64 * sizeof(float)));
+    e->ws_rows = rows;
+  }
+  if (logit_rows > e->ws_logit_rows) {
+    MI_HIP(hipStreamSynchronize(e->stream));
+    hipFree(e->logits);
+    MI_HIP(hipMalloc(&e->logits, logit_rows * (size_t)d.vocab_size * sizeof(float)));
+    e->ws_logit_rows = logit_rows;
+  }
+  if (rows > e->d_tokens_cap) {
+    MI_HIP(hipStreamSynchronize(e->stream));
+    hipFree(e->d_tokens);
+    MI_HIP(hipMalloc(&e->d_tokens, rows * sizeof(int32_t)));
+    e->d_tokens_cap = rows;
+  }
+  if (B > e->maxB) {
+    MI_HIP(hipStreamSynchronize(e->stream));
+    hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats); hipFree(e->d_uniforms);
+    hipFree(e->d_topk_ids); hipFree(e->d_topk_lp);
+    MI_HIP(hipMalloc(&e->d_next, B * sizeof(int32_t)));
+    MI_HIP(hipMalloc(&e->d_logprob, B * sizeof(float)));
+    MI_HIP(hipMalloc(&e->d_prob0, B * sizeof(float)));
+    MI_HIP(hipMalloc(&e->d_rowstats, 2 * B * sizeof(float)));
+    MI_HIP(hipMalloc(&e->d_uniforms, B * sizeof(float)));
+    MI_HIP(hipMalloc(&e->d_topk_ids, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(int32_t)));
+    MI_HIP(hipMalloc(&e->d_topk_lp, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(float)));
+    for (auto& s : e->slots) {
+      hipHostFree(s.tokens); hipHostFree(s.logprob); hipHostFree(s.prob0); hipHostFree(s.topk_ids); hipHostFree(s.topk_lp);
+      MI_HIP(hipHostMalloc(&s.tokens, B * sizeof(int32_t)));
+      MI_HIP(hipHostMalloc(&s.logprob, B * sizeof(float)));
+      MI_HIP(hipHostMalloc(&s.prob0, B * sizeof(float)));
+      MI_HIP(hipHostMalloc(&s.topk_ids, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(int32_t)));
+      MI_HIP(hipHostMalloc(&s.topk_lp, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(float)));
+      if (!s.ev) MI_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    }
+    e->maxB = B;
+  }
+  return MI_OK;
+}
+
+// y = W x for `rows` rows, split into launches of at most 16 (MFMA) / 8 (generic) rows
+int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_t es_in, size_t es_out,
+              const char* prof) {
+  Prof pr(e, prof);
+  c.force_v1 = e->opt_force_v1;
+  const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
+  GemvCall probe = c; probe.M = (int)std::min<size_t>(rows, 16);
+  const size_t step = gemv_mfma_supported(f.W, probe) ? 16 : 8;
+  const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
+  for (size_t r = 0; r < rows; r += step) {
+    GemvCall cc = c;
+    cc.M = (int)std::min(step, rows - r);
+    cc.x = x0 + r * (size_t)c.ldx * es_in;
+    if (o0) cc.out = o0 + r * (size_t)c.ldo * es_out;
+    if (r0) cc.resid = r0 + r * (size_t)c.ldo * es_in;
+    if (has_lora) {
+      cc.lora_t = e->lora_t + r * 128; cc.lora_t_ld = 128;
+      MI_TRY(launch_lora_down(f.W, cc, e->lora_t + r * 128, 128, e->stream));
+    }
+    MI_TRY(launch_gemv(f.W, cc, e->stream));
+  }
+  return MI_OK;
+}
+
+int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L) {
+  if (L != 1) return 1;
+  int mx = 0;
+  for (int b = 0; b < B; ++b) mx = std::max(mx, kv->h_off[b] + 1);
+  int ns = (256 + B * Hkv - 1) / (B * Hkv);
+  ns = std::min(ns, std::max(1, mx / 64));
+  return std::max(1, std::min(ns, 16));
+}
+
+// the model forward for B*L tokens already in e->d_tokens; logits of the requested rows end
+// up in e->logits (float32, [B][V] or [B*L][V]).
+int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool want_logits) {
+  const mi_model_desc& d = e->d;
+  const size_t R = (size_t)B * L;
+  const bool quirk = kv->quirk;
+  const int act = quirk ? MI_F32 : d.act_dtype;
+  const size_t es = dtype_size(act);
+  const int rndT = quirk ? (d.act_dtype == MI_BF16 ? RND_BF16 : RND_F16) : RND_NONE;
+  const int H = d.hidden_size, D = d.head_dim, Hq = d.num_heads, Hkv = d.num_kv_heads, I = d.intermediate_size;
+  const int nqkv = (Hq + 2 * Hkv) * D;
+  hipStream_t st = e->stream;
+
+  for (int b = 0; b < B; ++b)
+    if (kv->h_off[b] + L > kv->cap || kv->h_off[b] + L > d.max_positions)
+      return fail(MI_ERR_INVALID, "forward: KV capacity / max_positions exceeded (call mi_kv_reserve)");
+
+  { Prof pr(e, "embed");
+    EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
+    MI_TRY(launch_embed(e->embed.W, ec, st)); }
+
+  const size_t layer_elems = (size_t)kv->B * Hkv * kv->cap * D;
+  const size_t kes = dtype_size(kv->dtype);
+  const int nsplit = choose_nsplit(kv, B, Hkv, L);
+  if (nsplit > 1) {
+    const size_t need = R * Hq * nsplit * (D + 2);
+    if (kv->partial == nullptr || kv->partial_splits < nsplit) {
+      MI_HIP(hipStreamSynchronize(st));
+      hipFree(kv->partial);
+      MI_HIP(hipMalloc(&kv->partial, (size_t)kv->B * Hq * 16 * (D + 2) * sizeof(float)));
+      kv->partial_splits = 16;
+    }
+    (void)need;
+  }
+
+  for (int li = 0; li < d.num_layers; ++li) {
+    LayerW& lw = e->layers[li];
+    // everything up to the layer-0 attention still rounds to the model dtype in quirk mode
+    const int rnd = (quirk && li == 0) ? rndT : RND_NONE;
+    {  // input_layernorm + q|k|v projections (llama.py:187,93)
+      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = rnd; c.pro = PRO_NORM; c.norm_w = lw.in_norm;
+      c.eps = d.rms_norm_eps; c.epi = EPI_STORE; c.out = e->qkv; c.ldo = nqkv;
+      MI_TRY(gemv_rows(e, lw.qkv, c, R, es, es, "gemv_qkv"));
+    }
+    AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap};
+    void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
+    void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
+    { Prof pr(e, "rope_append");
+      RopeAppendCall rc{s, e->qkv, e->q, kc, vc, kv->d_off, lw.q_norm, lw.k_norm, d.rms_norm_eps,
+                        e->cos_tab, e->sin_tab, d.max_positions};
+      MI_TRY(launch_rope_append(rc, st)); }
+    { Prof pr(e, "attn");
+      AttnShape sa = s; sa.rnd = RND_NONE;  // SDPA output dtype = promote(q, kv): float32 in quirk mode
+      AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial};
+      MI_TRY(launch_attention(ac, st)); }
+    {  // o_proj + residual (llama.py:143,188)
+      GemvCall c; c.x = e->attn; c.ldx = Hq * D; c.act = act; c.rnd = RND_NONE; c.epi = EPI_RESID;
+      c.resid = e->h; c.ldo = H;
+      MI_TRY(gemv_rows(e, lw.o, c, R, es, es, "gemv_o"));
+    }
+    {  // post_attention_layernorm + gate|up + SwiGLU (llama.py:189,165)
+      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = lw.post_norm;
+      c.eps = d.rms_norm_eps; c.epi = EPI_SWIGLU; c.out = e->act; c.ldo = I; c.pair_offset = I;
+      MI_TRY(gemv_rows(e, lw.gate_up, c, R, es, es, "gemv_gate_up"));
+    }
+    {  // down_proj + residual (llama.py:165,190)
+      GemvCall c; c.x = e->act; c.ldx = I; c.act = act; c.rnd = RND_NONE; c.epi = EPI_RESID; c.resid = e->h; c.ldo = H;
+      MI_TRY(gemv_rows(e, lw.down, c, R, es, es, "gemv_down"));
+    }
+  }
+  if (want_logits) {  // final norm + lm_head / tied embedding (llama.py:231,249-252)
+    const FusedLinear& head = d.tie_word_embeddings ? e->embed : e->lm_head;
+    GemvCall c; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = e->final_norm; c.eps = d.rms_norm_eps;
+    c.epi = EPI_STORE_F32; c.out = e->logits; c.ldo = d.vocab_size;
+    if (all_pos) { c.x = e->h; c.ldx = H; MI_TRY(gemv_rows(e, head, c, R, es, sizeof(float), "gemv_head")); }
+    else { c.x = (char*)e->h + (size_t)(L - 1) * H * es; c.ldx = L * H; MI_TRY(gemv_rows(e, head, c, B, es, sizeof(float), "gemv_head")); }
+  }
+  MI_TRY(launch_advance_offsets(kv->d_off, B, L, st));
+  for (int b = 0; b < B; ++b) kv->h_off[b] += L;
+  return MI_OK;
+}
+
+int check_call(mi_engine* e, mi_kv* kv, int B, int L) {
+  if (!e || !kv) return fail(MI_ERR_INVALID, "null handle");
+  if (!e->finalized) return fail(MI_ERR_INVALID, "engine not finalized");
+  if (kv->e != e) return fail(MI_ERR_INVALID, "kv belongs to another engine");
+  if (B != kv->B) return fail(MI_ERR_INVALID, "batch size mismatch (PagedKVCache batch size mismatch, base.py:125)");
+  if (L < 1) return fail(MI_ERR_INVALID, "L must be >= 1");
+  MI_HIP(hipSetDevice(e->device));
+  return MI_OK;
+}
+
+int upload_tokens(mi_engine* e, const int32_t* tokens, int B, int L) {
+  const size_t R = (size_t)B * L;
+  for (size_t i = 0; i < R; ++i)
+    if (tokens[i] < 0 || tokens[i] >= e->d.vocab_size) return fail(MI_ERR_INVALID, "token id out of range");
+  MI_HIP(hipMemcpyAsync(e->d_tokens, tokens, R * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  return MI_OK;
+}
+
+int run_sample(mi_engine* e, int B, const mi_sample_params* sp) {
+  mi_sample_params def{}; def.temperature = 0.f; def.top_p = 1.f;
+  if (!sp) sp = &def;
+  hipStream_t st = e->stream;
+  if (sp->n_logit_bias > 0) {
+    if (sp->n_logit_bias > 4096) return fail(MI_ERR_INVALID, "too many logit_bias entries");
+    if (!e->d_bias_ids) { MI_HIP(hipMalloc(&e->d_bias_ids, 4096 * sizeof(int32_t))); MI_HIP(hipMalloc(&e->d_bias_vals, 4096 * sizeof(float))); }
+    MI_HIP(hipMemcpyAsync(e->d_bias_ids, sp->logit_bias_ids, sp->n_logit_bias * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(e->d_bias_vals, sp->logit_bias_values, sp->n_logit_bias * sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  if (sp->uniforms) MI_HIP(hipMemcpyAsync(e->d_uniforms, sp->uniforms, B * sizeof(float), hipMemcpyHostToDevice, st));
+  Prof pr(e, "sample");
+  SampleCall sc{};
+  sc.logits = e->logits; sc.B = B; sc.V = e->d.vocab_size; sc.rnd = RND_NONE;
+  sc.temperature = sp->temperature; sc.top_p = sp->top_p;
+  sc.n_bias = sp->n_logit_bias; sc.bias_ids = e->d_bias_ids; sc.bias_vals = e->d_bias_vals;
+  sc.uniforms = sp->uniforms ? e->d_uniforms : nullptr; sc.seed = sp->seed; sc.step = e->step_counter++;
+  sc.top_logprobs = sp->top_logprobs;
+  sc.tokens_out = e->d_next; sc.logprob_out = e->d_logprob; sc.prob_row0_out = e->d_prob0;
+  sc.topk_ids = e->d_topk_ids; sc.topk_logprobs = e->d_topk_lp; sc.row_stats = e->d_rowstats;
+  return launch_sample(sc, st);
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char* mi_last_error(void) { return g_err.c_str(); }
+const char* mi_version(void) { return "mi355_decode 0.1 (gfx950)"; }
+
+int mi_engine_create(const mi_model_desc* desc, int device, mi_engine** out) {
+  if (!desc || !out) return fail(MI_ERR_INVALID, "null argument");
+  const mi_model_desc& d = *desc;
+  if (d.arch != MI_ARCH_LLAMA && d.arch != MI_ARCH_QWEN3) return fail(MI_ERR_UNSUPPORTED, "unsupported arch");
+  if (d.hidden_size <= 0 || d.num_layers <= 0 || d.num_heads <= 0 || d.num_kv_heads <= 0 || d.head_dim <= 0 ||
+      d.intermediate_size <= 0 || d.vocab_size <= 0 || d.max_positions <= 0)
+    return fail(MI_ERR_INVALID, "model dimensions must be positive");
+  if (d.num_heads % d.num_kv_heads != 0) return fail(MI_ERR_INVALID, "num_heads must be a multiple of num_kv_heads");
+  if (d.act_dtype != MI_F32 && d.act_dtype != MI_BF16 && d.act_dtype != MI_F16) return fail(MI_ERR_INVALID, "bad act_dtype");
+  if (d.quant_bits != 0 && d.quant_bits != 4 && d.quant_bits != 8) return fail(MI_ERR_UNSUPPORTED, "quant_bits must be 0, 4 or 8");
+  if (d.hidden_size % 8 || d.intermediate_size % 8 || (d.num_heads * d.head_dim) % 8)
+    return fail(MI_ERR_UNSUPPORTED, "hidden / intermediate sizes must be multiples of 8");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MI_ERR_RUNTIME, "no HIP device available (this library has no CPU backend)");
+  if (device < 0 || device >= ndev) return fail(MI_ERR_INVALID, "bad device index");
+  MI_HIP(hipSetDevice(device));
+  mi_engine* e = new mi_engine();
+  e->d = d; e->device = device;
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(MI_ERR_RUNTIME, "hipStreamCreate failed"); }
+  e->layers.resize(d.num_layers);
+  const int D = d.head_dim;
+  for (auto& l : e->layers) {
+    l.qkv.n_parts = 3; l.qkv.part_rows[0] = d.num_heads * D; l.qkv.part_rows[1] = d.num_kv_heads * D; l.qkv.part_rows[2] = d.num_kv_heads * D;
+    l.o.n_parts = 1; l.o.part_rows[0] = d.hidden_size;
+    l.gate_up.n_parts = 2; l.gate_up.part_rows[0] = d.intermediate_size; l.gate_up.part_rows[1] = d.intermediate_size;
+    l.down.n_parts = 1; l.down.part_rows[0] = d.hidden_size;
+  }
+  e->embed.n_parts = 1; e->embed.part_rows[0] = d.vocab_size;
+  e->lm_head.n_parts = 1; e->lm_head.part_rows[0] = d.vocab_size;
+  *out = e;
+  return MI_OK;
+}
+
+void mi_engine_destroy(mi_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  for (auto& l : e->layers) {
+    free_linear(l.qkv); free_linear(l.o); free_linear(l.gate_up); free_linear(l.down);
+    hipFree(l.in_norm); hipFree(l.post_norm); hipFree(l.q_norm); hipFree(l.k_norm);
+  }
+  free_linear(e->embed); free_linear(e->lm_head);
+  hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
+  hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t);
+  hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
+  hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
+  for (auto& s : e->slots) {
+    hipHostFree(s.tokens); hipHostFree(s.logprob); hipHostFree(s.prob0); hipHostFree(s.topk_ids); hipHostFree(s.topk_lp);
+    if (s.ev) hipEventDestroy(s.ev);
+  }
+  for (auto& p : e->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mi_engine_set_tensor(mi_engine* e, const char* name_c, const void* data, const int64_t* shape, int ndim,
+                         int dtype, int on_device) {
+  if (!e || !name_c || !data || !shape) return fail(MI_ERR_INVALID, "null argument");
+  if (e->finalized) return fail(MI_ERR_INVALID, "engine already finalized");
+  MI_HIP(hipSetDevice(e->device));
+  const mi_model_desc& d = e->d;
+  std::string name(name_c);
+  int kind = -1;
+  std::string base;
+  auto strip = [&](const char* suf, int k) {
+    const size_t n = strlen(suf);
+    if (name.size() > n && name.compare(name.size() - n, n, suf) == 0) { base = name.substr(0, name.size() - n); kind = k; }
+  };
+  strip(".weight", 0); strip(".scales", 1); strip(".biases", 2);
+  if (kind < 0) return fail(MI_ERR_NOTFOUND, "unknown tensor: " + name);
+  const int H = d.hidden_size, I = d.intermediate_size, QD = d.num_heads * d.head_dim;
+  if (base == "model.embed_tokens") return set_linear(e, e->embed, 0, H, kind, data, shape, ndim, dtype, on_device, name);
+  if (base == "lm_head") {
+    if (d.tie_word_embeddings) return fail(MI_ERR_NOTFOUND, "lm_head given but tie_word_embeddings is set: " + name);
+    return set_linear(e, e->lm_head, 0, H, kind, data, shape, ndim, dtype, on_device, name);
+  }
+  if (base == "model.norm" && kind == 0) return set_vector(e, e->final_norm, H, data, shape, ndim, dtype, on_device, name);
+  const std::string pre = "model.layers.";
+  if (base.compare(0, pre.size(), pre) != 0) return fail(MI_ERR_NOTFOUND, "unknown tensor: " + name);
+  const size_t dot = base.find('.', pre.size());
+  if (dot == std::string::npos) return fail(MI_ERR_NOTFOUND, "unknown tensor: " + name);
+  int li = -1;
+  try { li = std::stoi(base.substr(pre.size(), dot - pre.size())); } catch (...) { li = -1; }
+  if (li < 0 || li >= d.num_layers) return fail(MI_ERR_NOTFOUND, "layer index out of range: " + name);
+  const std::string sub = base.substr(dot + 1);
+  LayerW& l = e->layers[li];
+  if (sub == "self_attn.q_proj") return set_linear(e, l.qkv, 0, H, kind, data, shape, ndim, dtype, on_device, name);
+  if (sub == "self_attn.k_proj") return set_linear(e, l.qkv, 1, H, kind, data, shape, ndim, dtype, on_device, name);
+  if (sub == "self_attn.v_proj") return set_linear(e, l.qkv, 2, H, kind, data, shape, ndim, dtype, on_device, name);
+  if (sub == "self_attn.o_proj") return set_linear(e, l.o, 0, QD, kind, data, shape, ndim, dtype, on_device, name);
+  if (sub == "mlp.gate_proj") return set_linear(e, l.gate_up, 0, H, kind, data, shape, ndim, dtype, on_device, name);
+  if (sub == "mlp.up_proj") return set_linear(e, l.gate_up, 1, H, kind, data, shape, ndim, dtype, on_device, name);
+  if (sub == "mlp.down_proj") return set_linear(e, l.down, 0, I, kind, data, shape, ndim, dtype, on_device, name);
+  if (kind == 0) {
+    if (sub == "input_layernorm") return set_vector(e, l.in_norm, H, data, shape, ndim, dtype, on_device, name);
+    if (sub == "post_attention_layernorm") return set_vector(e, l.post_norm, H, data, shape, ndim, dtype, on_device, name);
+    if (d.arch == MI_ARCH_QWEN3 && sub == "self_attn.q_norm") return set_vector(e, l.q_norm, d.head_dim, data, shape, ndim, dtype, on_device, name);
+    if (d.arch == MI_ARCH_QWEN3 && sub == "self_attn.k_norm") return set_vector(e, l.k_norm, d.head_dim, data, shape, ndim, dtype, on_device, name);
+  }
+  return fail(MI_ERR_NOTFOUND, "unknown tensor: " + name);
+}
+
+int mi_engine_set_lora(mi_engine* e, int layer, const char* proj, const void* A, const void* B, int rank, float scale,
+                       int dtype, int on_device) {
+  if (!e || !proj || !A || !B) return fail(MI_ERR_INVALID, "null argument");
+  if (layer < 0 || layer >= e->d.num_layers) return fail(MI_ERR_INVALID, "layer out of range");
+  if (rank < 1 || rank > 64) return fail(MI_ERR_UNSUPPORTED, "LoRA rank must be in [1,64]");
+  if (dtype != MI_F32 && dtype != MI_BF16 && dtype != MI_F16) return fail(MI_ERR_INVALID, "bad LoRA dtype");
+  if (dtype != MI_F32 && dtype != e->d.act_dtype) return fail(MI_ERR_UNSUPPORTED, "LoRA dtype must be float32 or the model dtype");
+  if (dtype != MI_F32) return fail(MI_ERR_UNSUPPORTED, "16-bit LoRA factors are not supported yet (float32 only)");
+  MI_HIP(hipSetDevice(e->device));
+  const mi_model_desc& d = e->d;
+  LayerW& l = e->layers[layer];
+  const std::string p(proj);
+  FusedLinear* f = nullptr; int row0 = 0, n = 0, K = d.hidden_size;
+  const int QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim;
+  if (p == "self_attn.q_proj") { f = &l.qkv; row0 = 0; n = QD; }
+  else if (p == "self_attn.k_proj") { f = &l.qkv; row0 = QD; n = KD; }
+  else if (p == "self_attn.v_proj") { f = &l.qkv; row0 = QD + KD; n = KD; }
+  else if (p == "self_attn.o_proj") { f = &l.o; row0 = 0; n = d.hidden_size; K = QD; }
+  else if (p == "mlp.down_proj") { f = &l.down; row0 = 0; n = d.hidden_size; K = d.intermediate_size; }
+  else return fail(MI_ERR_UNSUPPORTED, "LoRA on " + p + " is not supported (q/k/v/o/down only)");
+  int slot = -1;
+  for (int i = 0; i < 2; ++i) if (f->lora_b[i] != nullptr && f->W.lora_row0[i] == row0) slot = i;   // hot-swap
+  if (slot < 0) for (int i = 0; i < 2; ++i) if (f->lora_b[i] == nullptr) { slot = i; break; }
+  if (slot < 0) return fail(MI_ERR_UNSUPPORTED, "at most two adapted projections per fused matrix");
+  MI_HIP(hipStreamSynchronize(e->stream));
+  hipFree(f->lora_a[slot]); hipFree(f->lora_b[slot]);
+  f->lora_a[slot] = f->lora_b[slot] = nullptr;
+  MI_HIP(hipMalloc(&f->lora_a[slot], (size_t)K * rank * sizeof(float)));
+  MI_HIP(hipMalloc(&f->lora_b[slot], (size_t)rank * n * sizeof(float)));
+  MI_TRY(copy_in(f->lora_a[slot], A, (size_t)K * rank * sizeof(float), on_device, e->stream));
+  MI_TRY(copy_in(f->lora_b[slot], B, (size_t)rank * n * sizeof(float), on_device, e->stream));
+  f->W.lora_a[slot] = f->lora_a[slot]; f->W.lora_b[slot] = f->lora_b[slot];
+  f->W.lora_row0[slot] = row0; f->W.lora_n[slot] = n; f->W.lora_rank[slot] = rank; f->W.lora_scale[slot] = scale;
+  return MI_OK;
+}
+
+int mi_engine_finalize(mi_engine* e) {
+  if (!e) return fail(MI_ERR_INVALID, "null engine");
+  if (e->finalized) return MI_OK;
+  MI_HIP(hipSetDevice(e->device));
+  const mi_model_desc& d = e->d;
+  const int H = d.hidden_size, QD = d.num_heads * d.head_dim;
+  for (int i = 0; i < d.num_layers; ++i) {
+    LayerW& l = e->layers[i];
+    const std::string p = "model.layers." + std::to_string(i);
+    MI_TRY(finalize_linear(e, l.qkv, H, p + ".self_attn.{q,k,v}_proj"));
+    MI_TRY(finalize_linear(e, l.o, QD, p + ".self_attn.o_proj"));
+    MI_TRY(finalize_linear(e, l.gate_up, H, p + ".mlp.{gate,up}_proj"));
+    MI_TRY(finalize_linear(e, l.down, d.intermediate_size, p + ".mlp.down_proj"));
+    if (!l.in_norm || !l.post_norm) return fail(MI_ERR_NOTFOUND, p + ": layernorm weights not set");
+    if (d.arch == MI_ARCH_QWEN3 && (!l.q_norm || !l.k_norm)) return fail(MI_ERR_NOTFOUND, p + ": q_norm/k_norm not set");
+  }
+  MI_TRY(finalize_linear(e, e->embed, H, "model.embed_tokens"));
+  if (!d.tie_word_embeddings) MI_TRY(finalize_linear(e, e->lm_head, H, "lm_head"));
+  if (!e->final_norm) return fail(MI_ERR_NOTFOUND, "model.norm.weight not set");
+  const size_t n = (size_t)d.max_positions * (d.head_dim / 2);
+  MI_HIP(hipMalloc(&e->cos_tab, n * sizeof(float)));
+  MI_HIP(hipMalloc(&e->sin_tab, n * sizeof(float)));
+  MI_TRY(launch_rope_tables(e->cos_tab, e->sin_tab, d.max_positions, d.head_dim, d.rope_theta, d.rope_scale, e->stream));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  e->finalized = true;
+  return MI_OK;
+}
+
+// ---- KV ---------------------------------------------------------------------------------
+int mi_kv_create(mi_engine* e, int batch, int capacity_tokens, int kv_dtype, mi_kv** out) {
+  if (!e || !out) return fail(MI_ERR_INVALID, "null argument");
+  if (batch < 1 || capacity_tokens < 1) return fail(MI_ERR_INVALID, "batch and capacity must be positive");
+  if (capacity_tokens > e->d.max_positions) return fail(MI_ERR_INVALID, "capacity exceeds desc.max_positions");
+  MI_HIP(hipSetDevice(e->device));
+  mi_kv* kv = new mi_kv();
+  kv->e = e; kv->B = batch; kv->cap = capacity_tokens;
+  if (kv_dtype == MI_KV_MODEL || kv_dtype == e->d.act_dtype) { kv->dtype = e->d.act_dtype; kv->quirk = false; }
+  else if (kv_dtype == MI_F32) { kv->dtype = MI_F32; kv->quirk = true; }
+  else { delete kv; return fail(MI_ERR_UNSUPPORTED, "kv dtype must be the model dtype or float32"); }
+  const size_t bytes = (size_t)e->d.num_layers * batch * e->d.num_kv_heads * capacity_tokens * e->d.head_dim * dtype_size(kv->dtype);
+  if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess ||
+      hipMalloc(&kv->d_off, batch * sizeof(int32_t)) != hipSuccess) {
+    hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); delete kv;
+    return fail(MI_ERR_RUNTIME, "out of device memory allocating the KV cache");
+  }
+  // zero-filled like the reference's mx.zeros (base.py:71-72,111-112)
+  MI_HIP(hipMemsetAsync(kv->k, 0, bytes, e->stream));
+  MI_HIP(hipMemsetAsync(kv->v, 0, bytes, e->stream));
+  MI_HIP(hipMemsetAsync(kv->d_off, 0, batch * sizeof(int32_t), e->stream));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  kv->h_off.assign(batch, 0);
+  *out = kv;
+  return MI_OK;
+}
+
+void mi_kv_destroy(mi_kv* kv) {
+  if (!kv) return;
+  hipSetDevice(kv->e->device);
+  hipStreamSynchronize(kv->e->stream);
+  hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->partial);
+  delete kv;
+}
+
+int mi_kv_reset(mi_kv* kv, int batch) {
+  if (!kv) return fail(MI_ERR_INVALID, "null kv");
+  if (batch != kv->B) return fail(MI_ERR_INVALID, "mi_kv_reset: batch differs from the allocated batch (create a new kv)");
+  MI_HIP(hipSetDevice(kv->e->device));
+  MI_HIP(hipMemsetAsync(kv->d_off, 0, kv->B * sizeof(int32_t), kv->e->stream));
+  MI_HIP(hipStreamSynchronize(kv->e->stream));
+  std::fill(kv->h_off.begin(), kv->h_off.end(), 0);
+  return MI_OK;
+}
+
+int mi_kv_reserve(mi_kv* kv, int capacity_tokens) {
+  if (!kv) return fail(MI_ERR_INVALID, "null kv");
+  if (capacity_tokens <= kv->cap) return MI_OK;
+  mi_engine* e = kv->e;
+  if (capacity_tokens > e->d.max_positions) return fail(MI_ERR_INVALID, "capacity exceeds desc.max_positions");
+  MI_HIP(hipSetDevice(e->device));
+  const size_t es = dtype_size(kv->dtype);
+  const size_t slabs = (size_t)e->d.num_layers * kv->B * e->d.num_kv_heads;
+  const size_t old_pitch = (size_t)kv->cap * e->d.head_dim * es, new_pitch = (size_t)capacity_tokens * e->d.head_dim * es;
+  void* nk = nullptr; void* nv = nullptr;
+  if (hipMalloc(&nk, slabs * new_pitch) != hipSuccess || hipMalloc(&nv, slabs * new_pitch) != hipSuccess) {
+    hipFree(nk); hipFree(nv);
+    return fail(MI_ERR_RUNTIME, "out of device memory growing the KV cache");
+  }
+  MI_HIP(hipMemsetAsync(nk, 0, slabs * new_pitch, e->stream));
+  MI_HIP(hipMemsetAsync(nv, 0, slabs * new_pitch, e->stream));
+  MI_HIP(hipMemcpy2DAsync(nk, new_pitch, kv->k, old_pitch, old_pitch, slabs, hipMemcpyDeviceToDevice, e->stream));
+  MI_HIP(hipMemcpy2DAsync(nv, new_pitch, kv->v, old_pitch, old_pitch, slabs, hipMemcpyDeviceToDevice, e->stream));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  hipFree(kv->k); hipFree(kv->v);
+  kv->k = nk; kv->v = nv; kv->cap = capacity_tokens;
+  return MI_OK;
+}
+
+int mi_kv_offsets(const mi_kv* kv, int32_t* out) {
+  if (!kv || !out) return fail(MI_ERR_INVALID, "null argument");
+  for (int b = 0; b < kv->B; ++b) out[b] = kv->h_off[b];
+  return MI_OK;
+}
+
+int mi_kv_capacity(const mi_kv* kv) { return kv ? kv->cap : 0; }
+
+// ---- forward / sampling --------------------------------------------------------------------
+int mi_forward(mi_engine* e, mi_kv* kv, const int32_t* tokens, int B, int L, float* logits_out, int all_pos) {
+  MI_TRY(check_call(e, kv, B, L));
+  if (!tokens) return fail(MI_ERR_INVALID, "null tokens");
+  const size_t R = (size_t)B * L;
+  MI_TRY(ensure_workspace(e, R, all_pos ? R : (size_t)B, B));
+  MI_TRY(upload_tokens(e, tokens, B, L));
+  MI_TRY(forward_device(e, kv, B, L, all_pos != 0, logits_out != nullptr));
+  if (logits_out)
+    MI_HIP(hipMemcpyAsync(logits_out, e->logits, (all_pos ? R : (size_t)B) * e->d.vocab_size * sizeof(float),
+                          hipMemcpyDeviceToHost, e->stream));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  return MI_OK;
+}
+
+int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L, const mi_sample_params* sp,
+                    int64_t* ticket) {
+  MI_TRY(check_call(e, kv, B, L));
+  if (!ticket) return fail(MI_ERR_INVALID, "null ticket");
+  if (!tokens_in && L != 1) return fail(MI_ERR_INVALID, "device-resident token feed needs L == 1");
+  if (!tokens_in && e->maxB < B) return fail(MI_ERR_INVALID, "no previous step to take tokens from");
+  MI_TRY(ensure_workspace(e, (size_t)B * L, (size_t)B, B));
+  hipStream_t st = e->stream;
+  if (tokens_in) MI_TRY(upload_tokens(e, tokens_in, B, L));
+  else MI_HIP(hipMemcpyAsync(e->d_tokens, e->d_next, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  MI_TRY(forward_device(e, kv, B, L, false, true));
+  MI_TRY(run_sample(e, B, sp));
+  const int64_t t = e->next_ticket++;
+  Slot& s = e->slots[t % NSLOT];
+  s.B = B; s.topk = sp ? sp->top_logprobs : 0; s.ticket = t;
+  MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipMemcpyAsync(s.logprob, e->d_logprob, B * sizeof(float), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipMemcpyAsync(s.prob0, e->d_prob0, B * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (s.topk > 0) {
+    MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)B * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)B * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  MI_HIP(hipEventRecord(s.ev, st));
+  *ticket = t;
+  return MI_OK;
+}
+
+int mi_step_wait(mi_engine* e, int64_t ticket, int32_t* tokens_out, float* logprob_out, float* prob_row0_out,
+                 int32_t* topk_ids, float* topk_logprobs) {
+  if (!e) return fail(MI_ERR_INVALID, "null engine");
+  if (ticket < 0 || ticket >= e->next_ticket) return fail(MI_ERR_INVALID, "unknown ticket");
+  Slot& s = e->slots[ticket % NSLOT];
+  if (s.ticket != ticket) return fail(MI_ERR_INVALID, "ticket expired (more than 4 steps in flight)");
+  MI_HIP(hipSetDevice(e->device));
+  MI_HIP(hipEventSynchronize(s.ev));
+  if (tokens_out) memcpy(tokens_out, s.tokens, s.B * sizeof(int32_t));
+  if (logprob_out) memcpy(logprob_out, s.logprob, s.B * sizeof(float));
+  if (prob_row0_out) memcpy(prob_row0_out, s.prob0, s.B * sizeof(float));
+  if (topk_ids && s.topk > 0) memcpy(topk_ids, s.topk_ids, (size_t)s.B * s.topk * sizeof(int32_t));
+  if (topk_logprobs && s.topk > 0) memcpy(topk_logprobs, s.topk_lp, (size_t)s.B * s.topk * sizeof(float));
+  return MI_OK;
+}
+
+int mi_decode_sample(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L, const mi_sample_params* sp,
+                     int32_t* tokens_out, float* logprob_out, float* prob_row0_out, int32_t* topk_ids,
+                     float* topk_logprobs) {
+  int64_t t = -1;
+  MI_TRY(mi_step_enqueue(e, kv, tokens_in, B, L, sp, &t));
+  return mi_step_wait(e, t, tokens_out, logprob_out, prob_row0_out, topk_ids, topk_logprobs);
+}
+
+// ---- measurement hooks ----------------------------------------------------------------------
+int mi_profile_select(mi_engine* e, const char* name) {
+  if (!e) return fail(MI_ERR_INVALID, "null engine");
+  hipStreamSynchronize(e->stream);
+  for (auto& p : e->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  e->prof_events.clear();
+  e->prof_name = name ? name : "";
+  return MI_OK;
+}
+
+int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms) {
+  if (!e || !n_launches || !total_ms) return fail(MI_ERR_INVALID, "null argument");
+  MI_HIP(hipStreamSynchronize(e->stream));
+  double tot = 0.0;
+  for (auto& p : e->prof_events) {
+    float ms = 0.f;
+    MI_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+    tot += ms;
+    hipEventDestroy(p.first); hipEventDestroy(p.second);
+  }
+  *n_launches = (int64_t)e->prof_events.size();
+  *total_ms = tot;
+  e->prof_events.clear();
+  return MI_OK;
+}
+
+int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
+  if (!e || !key) return fail(MI_ERR_INVALID, "null argument");
+  const std::string k(key);
+  if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
+  return fail(MI_ERR_NOTFOUND, "unknown option: " + k);
+}
+
+int mi_engine_sync(mi_engine* e) {
+  if (!e) return fail(MI_ERR_INVALID, "null engine");
+  MI_HIP(hipSetDevice(e->device));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  return MI_OK;
+}
+
+}  // extern "C"

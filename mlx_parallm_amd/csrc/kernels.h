@@ -1,0 +1,122 @@
+// kernels.h -- host-side launch interface of the HIP kernels (internal to the library).
+#pragma once
+#include "common.h"
+
+namespace mi {
+
+// One (possibly fused) weight matrix W[N][K] as the kernels see it.
+struct LinearW {
+  int wk = WK_F32;             // weight kind (common.h)
+  const void* w = nullptr;     // dense [N][K] or MLX-packed [N][K*bits/32] uint32
+  const void* scales = nullptr;  // [N][K/group] in the scale dtype
+  const void* biases = nullptr;
+  int N = 0, K = 0, group = 64;
+  // LoRA (mlx-lm LoRALinear): rows [lora_row0, lora_row0+lora_n) of this (fused) matrix get
+  // + scale * ((x A) B); A [K][r], B [r][lora_n] stored as float32.
+  const float* lora_a[2] = {nullptr, nullptr};
+  const float* lora_b[2] = {nullptr, nullptr};
+  int lora_row0[2] = {0, 0}, lora_n[2] = {0, 0}, lora_rank[2] = {0, 0};
+  float lora_scale[2] = {0.f, 0.f};
+};
+
+enum : int { PRO_NONE = 0, PRO_NORM = 1 };
+enum : int {
+  EPI_STORE = 0,      // out[m][n] = T(acc)
+  EPI_STORE_F32 = 1,  // out_f32[m][n] = float(T(acc))            (logits for the sampler)
+  EPI_RESID = 2,      // resid[m][n] = T(resid[m][n] + T(acc))     (h = x + r, llama.py:188,190)
+  EPI_SWIGLU = 3,     // out[m][n] = T(T(silu(g)) * u), g/u = rows n, n+pair_offset (llama.py:165)
+};
+
+struct GemvCall {
+  const void* x = nullptr;  // [M][ldx] activations (storage type `act`)
+  int ldx = 0;
+  int M = 0;
+  int act = MI_F32;         // storage type of x / out / resid / norm_w
+  int rnd = RND_NONE;       // logical rounding applied on top of the storage type
+  int pro = PRO_NONE;
+  const void* norm_w = nullptr;  // [K] RMSNorm weight (PRO_NORM)
+  float eps = 0.f;
+  int epi = EPI_STORE;
+  void* out = nullptr;
+  int ldo = 0;
+  void* resid = nullptr;
+  int pair_offset = 0;
+  const float* lora_t = nullptr;  // [M][2][max_rank] = round(x A) for the (up to 2) adapted row ranges
+  int lora_t_ld = 0;
+  int force_v1 = 0;
+};
+
+int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
+// t[m][slot][j] = round(sum_k x[m][k] A[k][j]) for the adapted ranges of W (same prologue as the gemv)
+int launch_lora_down(const LinearW& W, const GemvCall& c, float* t, int t_ld, hipStream_t st);
+
+struct EmbedCall {
+  const int32_t* tokens;  // device [rows]
+  int rows;
+  int act, rnd;
+  void* out;  // [rows][H]
+};
+int launch_embed(const LinearW& W, const EmbedCall& c, hipStream_t st);
+
+struct AttnShape {
+  int B, L, Hq, Hkv, D;
+  int act;      // storage type of qkv / q / out
+  int kv;       // storage type of the caches
+  int rnd;      // logical rounding of q, k (after norm / rope) and of the attention output
+  int cap;      // cache capacity (tokens)
+};
+struct RopeAppendCall {
+  AttnShape s;
+  const void* qkv;       // [B*L][(Hq+2Hkv)*D]
+  void* q_out;           // [B*L][Hq*D]
+  void* kcache;          // [B][Hkv][cap][D]
+  void* vcache;
+  const int32_t* offsets;  // device [B]: tokens already in the cache
+  const void* q_norm_w;  // [D] or null (qwen3.py:65-70)
+  const void* k_norm_w;
+  float eps;
+  const float* cos_tab;  // [max_pos][D/2]
+  const float* sin_tab;
+  int max_pos;
+};
+int launch_rope_append(const RopeAppendCall& c, hipStream_t st);
+
+struct AttnCall {
+  AttnShape s;
+  const void* q;         // [B*L][Hq*D] (normed + roped)
+  const void* kcache;
+  const void* vcache;
+  const int32_t* offsets;  // device [B]: tokens in the cache BEFORE this call's L were appended
+  void* out;             // [B*L][Hq*D]
+  float scale;
+  int nsplit;            // >1 only for L == 1
+  float* partial;        // [B*L*Hq][nsplit][D+2] when nsplit > 1
+};
+int launch_attention(const AttnCall& c, hipStream_t st);
+
+struct SampleCall {
+  float* logits;         // [B][V] float32 (modified in place by logit_bias)
+  int B, V;
+  int rnd;
+  float temperature, top_p;
+  int n_bias;
+  const int32_t* bias_ids;   // device
+  const float* bias_vals;    // device
+  const float* uniforms;     // device [B] or null
+  uint64_t seed, step;       // Philox key/counter when uniforms == null
+  int top_logprobs;
+  int32_t* tokens_out;       // device [B]
+  float* logprob_out;        // device [B]
+  float* prob_row0_out;      // device [B]
+  int32_t* topk_ids;         // device [B][top_logprobs]
+  float* topk_logprobs;
+  float* row_stats;          // device [B][2] scratch: (max, logsumexp)
+};
+int launch_sample(const SampleCall& c, hipStream_t st);
+
+int launch_advance_offsets(int32_t* offsets, int B, int L, hipStream_t st);
+int launch_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int D, float base, float scale,
+                       hipStream_t st);
+int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, size_t n, hipStream_t st);
+
+}  // namespace mi

@@ -1,0 +1,113 @@
+// ops_api.hip -- kernel-level C entry points (include/mi355_ops.h) on caller-owned device buffers.
+#include "../../include/mi355_ops.h"
+#include "kernels.h"
+
+namespace mi {
+int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
+bool gemv_mfma_supported(const LinearW& W, const GemvCall& c);
+}  // namespace mi
+
+using namespace mi;
+
+namespace {
+
+int ready() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MI_ERR_RUNTIME, "no HIP device available (this library has no CPU backend)");
+  return MI_OK;
+}
+
+int finish() {
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(nullptr));
+  return MI_OK;
+}
+
+LinearW to_linear(const mi_op_linear* w) {
+  LinearW W;
+  W.wk = w->wk; W.w = w->w; W.scales = w->scales; W.biases = w->biases; W.N = w->N; W.K = w->K;
+  W.group = w->group > 0 ? w->group : 64;
+  return W;
+}
+
+GemvCall to_call(const mi_op_gemv_args* a) {
+  GemvCall c;
+  c.x = a->x; c.ldx = a->ldx; c.M = a->M; c.act = a->act; c.rnd = a->rnd; c.pro = a->pro; c.norm_w = a->norm_w;
+  c.eps = a->eps; c.epi = a->epi; c.out = a->out; c.ldo = a->ldo; c.resid = a->resid; c.pair_offset = a->pair_offset;
+  c.force_v1 = a->force_generic;
+  return c;
+}
+
+AttnShape to_shape(const mi_op_attn_shape* s) {
+  return AttnShape{s->B, s->L, s->Hq, s->Hkv, s->D, s->act, s->kv, s->rnd, s->cap};
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a) {
+  if (!w || !a) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  const LinearW W = to_linear(w);
+  const GemvCall c = to_call(a);
+  const int maxm = gemv_mfma_supported(W, c) ? 16 : 8;
+  if (c.M < 1 || c.M > maxm) return fail(MI_ERR_INVALID, "mi_op_gemv: M out of range for this kernel");
+  MI_TRY(launch_gemv(W, c, nullptr));
+  return finish();
+}
+
+int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a) {
+  if (!w || !a) return 0;
+  return gemv_mfma_supported(to_linear(w), to_call(a)) ? 1 : 0;
+}
+
+int mi_op_embed(const mi_op_linear* w, const int32_t* tokens, int rows, int act, int rnd, void* out) {
+  if (!w || !tokens || !out) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  EmbedCall ec{tokens, rows, act, rnd, out};
+  MI_TRY(launch_embed(to_linear(w), ec, nullptr));
+  return finish();
+}
+
+int mi_op_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int head_dim, float base, float scale) {
+  MI_TRY(ready());
+  MI_TRY(launch_rope_tables(cos_tab, sin_tab, max_pos, head_dim, base, scale, nullptr));
+  return finish();
+}
+
+int mi_op_rope_append(const mi_op_attn_shape* s, const void* qkv, void* q_out, void* kcache, void* vcache,
+                      const int32_t* offsets, const void* q_norm_w, const void* k_norm_w, float eps,
+                      const float* cos_tab, const float* sin_tab, int max_pos) {
+  if (!s) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  RopeAppendCall rc{to_shape(s), qkv, q_out, kcache, vcache, offsets, q_norm_w, k_norm_w, eps, cos_tab, sin_tab, max_pos};
+  MI_TRY(launch_rope_append(rc, nullptr));
+  return finish();
+}
+
+int mi_op_attention(const mi_op_attn_shape* s, const void* q, const void* kcache, const void* vcache,
+                    const int32_t* offsets, void* out, float scale, int nsplit, float* partial) {
+  if (!s) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  AttnCall ac{to_shape(s), q, kcache, vcache, offsets, out, scale, nsplit, partial};
+  MI_TRY(launch_attention(ac, nullptr));
+  return finish();
+}
+
+int mi_op_sample(float* logits, int B, int V, float temperature, float top_p, const float* uniforms,
+                 int top_logprobs, int32_t* tokens_out, float* logprob_out, float* prob_row0_out,
+                 int32_t* topk_ids, float* topk_logprobs, float* row_stats) {
+  if (!logits || !tokens_out || !row_stats) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  SampleCall sc{};
+  sc.logits = logits; sc.B = B; sc.V = V; sc.rnd = RND_NONE; sc.temperature = temperature; sc.top_p = top_p;
+  sc.uniforms = uniforms; sc.seed = 0; sc.step = 0; sc.top_logprobs = top_logprobs;
+  sc.tokens_out = tokens_out; sc.logprob_out = logprob_out; sc.prob_row0_out = prob_row0_out;
+  sc.topk_ids = topk_ids; sc.topk_logprobs = topk_logprobs; sc.row_stats = row_stats;
+  MI_TRY(launch_sample(sc, nullptr));
+  return finish();
+}
+
+}  // extern "C"
