@@ -1,0 +1,279 @@
+"""Kernel-level parity (-m gpu): every HIP kernel against the oracle's restatement of the MLX
+op it replaces, through the C ABI of include/mi355_ops.h.
+
+Tolerances.  float32 activations: |err| <= 2e-5 * scale (fp32 accumulation order).  16-bit
+activations: results are rounded to the dtype at the same points as the oracle, so elements
+either match exactly or differ by one rounding step where the fp32 sums straddle a rounding
+boundary; we require >= 99 % of elements within 2 ulp AND every element within 4 ulp.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import numerics, ref_model, ref_quant, ref_sample
+from oracle.numerics import matmul_nt, round_to
+
+pytestmark = pytest.mark.gpu
+
+from mlx_parallm_amd import _lib as L  # noqa: E402
+from gpu_helpers import (MIDT, attn_shape, close_frac, dev, dev_i32, dev_u32, gemv, host, op_linear, ptr)  # noqa: E402
+
+RNG = np.random.default_rng(1234)
+
+
+def _assert_close(got, want, dtype, scale=1.0):
+    if dtype == "float32":
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * scale), np.abs(got - want).max()
+        return
+    assert close_frac(got, want, dtype, atol=1e-6 * scale) <= 0.01, close_frac(got, want, dtype)
+    ulp2 = {"bfloat16": 2.0 ** -6, "float16": 2.0 ** -9}[dtype]
+    assert np.all(np.abs(got - want) <= ulp2 * np.maximum(np.abs(want), 1e-2 * scale) + 1e-6), np.abs(got - want).max()
+
+
+def _make_weight(kind, N, K, act):
+    """-> (op_linear, dense float32 view the oracle multiplies with, keepalive tensors)."""
+    if kind in ("f32", "bf16", "f16"):
+        dt = {"f32": "float32", "bf16": "bfloat16", "f16": "float16"}[kind]
+        w = round_to(RNG.standard_normal((N, K)).astype(np.float32) * 0.05, dt)
+        wd = dev(w, dt)
+        return op_linear(kind, N, K, wd), w, [wd]
+    bits = 4 if kind.startswith("q4") else 8
+    sdt = {"f32": "float32", "bf16": "bfloat16", "f16": "float16"}[kind.split("_")[1]]
+    w = RNG.standard_normal((N, K)).astype(np.float32) * 0.05
+    packed, scales, biases = ref_quant.quantize(round_to(w, sdt), 64, bits, sdt)
+    pd, sd, bd = dev_u32(packed), dev(scales, sdt), dev(biases, sdt)
+    return op_linear(kind, N, K, pd, sd, bd), ref_quant.dequantize(packed, scales, biases, 64, bits), [pd, sd, bd]
+
+
+COMBOS = [
+    # (activation dtype, weight kind)
+    ("float32", "f32"), ("float32", "q4_f32"), ("float32", "q8_f32"), ("float32", "bf16"), ("float32", "q4_bf16"),
+    ("bfloat16", "bf16"), ("bfloat16", "q4_bf16"), ("bfloat16", "q8_bf16"),
+    ("float16", "f16"), ("float16", "q4_f16"), ("float16", "q8_f16"),
+]
+
+
+@pytest.mark.parametrize("force_generic", [1, 0])
+@pytest.mark.parametrize("M", [1, 3, 8])
+@pytest.mark.parametrize("act,kind", COMBOS)
+def test_gemv_norm_store(act, kind, M, force_generic):
+    """RMSNorm prologue + projection (llama.py:187 -> :93)."""
+    N, K = 80, 256
+    ol, wdense, keep = _make_weight(kind, N, K, act)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    nw = round_to(1.0 + 0.1 * RNG.standard_normal(K).astype(np.float32), act)
+    xn, _ = ref_model.rms_norm(x, act, nw, act, 1e-5)
+    want = round_to(matmul_nt(xn, wdense), act)
+    xd, nwd = dev(x, act), dev(nw, act)
+    out = torch.zeros((M, N), dtype=xd.dtype, device="cuda")
+    used = gemv(ol, xd, M, act, pro=L.PRO_NORM, norm_w=nwd, eps=1e-5, epi=L.EPI_STORE, out=out, ldo=N,
+                force_generic=force_generic)
+    if force_generic:
+        assert not used
+    _assert_close(host(out), want, act)
+
+
+@pytest.mark.parametrize("force_generic", [1, 0])
+@pytest.mark.parametrize("act,kind", [("float32", "f32"), ("float32", "q4_f32"), ("bfloat16", "bf16"),
+                                      ("bfloat16", "q4_bf16"), ("float16", "f16"), ("float16", "q4_f16")])
+def test_gemv_epilogues(act, kind, force_generic):
+    """residual add (llama.py:188,190), SwiGLU (llama.py:165), float32 logits store, K > one LDS chunk."""
+    M = 5
+    # --- residual: h = h + W x, K = 4608 spans several x chunks
+    N, K = 64, 4608
+    ol, wdense, keep = _make_weight(kind, N, K, act)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32) * 0.5, act)
+    h = round_to(RNG.standard_normal((M, N)).astype(np.float32), act)
+    r = round_to(matmul_nt(x, wdense), act)
+    want = round_to(h + r, act)
+    xd, hd = dev(x, act), dev(h, act)
+    gemv(ol, xd, M, act, epi=L.EPI_RESID, resid=hd, ldo=N, force_generic=force_generic)
+    _assert_close(host(hd), want, act, scale=4.0)
+    # --- SwiGLU over a fused gate|up matrix
+    I, K = 48, 256
+    ol, wdense, keep = _make_weight(kind, 2 * I, K, act)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    g = round_to(matmul_nt(x, wdense[:I]), act)
+    u = round_to(matmul_nt(x, wdense[I:]), act)
+    sig = round_to(1.0 / (1.0 + np.exp(-g.astype(np.float64))), act)
+    want = round_to(round_to(g * sig, act) * u, act)
+    xd = dev(x, act)
+    out = torch.zeros((M, I), dtype=xd.dtype, device="cuda")
+    gemv(ol, xd, M, act, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, force_generic=force_generic)
+    _assert_close(host(out), want, act)
+    # --- float32 logits (lm_head), odd N for the generic path / multiple of 16 for MFMA
+    N = 80 if not force_generic else 77
+    ol, wdense, keep = _make_weight(kind, N, K, act)
+    want = round_to(matmul_nt(x, wdense), act)
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    gemv(ol, xd, M, act, epi=L.EPI_STORE_F32, out=out, ldo=N, force_generic=force_generic)
+    _assert_close(host(out), want, act)
+
+
+@pytest.mark.parametrize("M", [9, 16])
+@pytest.mark.parametrize("act,kind", [("bfloat16", "bf16"), ("bfloat16", "q4_bf16"), ("float16", "q4_f16")])
+def test_gemv_mfma_16_rows(act, kind, M):
+    N, K = 96, 512
+    ol, wdense, keep = _make_weight(kind, N, K, act)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    want = round_to(matmul_nt(x, wdense), act)
+    xd = dev(x, act)
+    out = torch.zeros((M, N), dtype=xd.dtype, device="cuda")
+    used = gemv(ol, xd, M, act, epi=L.EPI_STORE, out=out, ldo=N)
+    assert used
+    _assert_close(host(out), want, act)
+
+
+def test_gemv_runtime_rounding_mode():
+    """float32 storage + bf16 logical rounding = the layer-0 half of the PagedKVCache quirk."""
+    M, N, K = 4, 40, 256
+    ol, wdense, keep = _make_weight("bf16", N, K, "float32")
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), "bfloat16")
+    nw = round_to(1.0 + 0.1 * RNG.standard_normal(K).astype(np.float32), "bfloat16")
+    xn, _ = ref_model.rms_norm(x, "bfloat16", nw, "bfloat16", 1e-6)
+    want = round_to(matmul_nt(xn, wdense), "bfloat16")
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    gemv(ol, dev(x), M, "float32", rnd=L.RND_BF16, pro=L.PRO_NORM, norm_w=dev(nw), eps=1e-6, epi=L.EPI_STORE,
+         out=out, ldo=N)
+    _assert_close(host(out), want, "bfloat16")
+
+
+@pytest.mark.parametrize("kind,act", [("f32", "float32"), ("bf16", "bfloat16"), ("q4_f32", "float32"),
+                                      ("q4_bf16", "bfloat16"), ("q8_f16", "float16")])
+def test_embed(kind, act):
+    V, H = 200, 128
+    ol, wdense, keep = _make_weight(kind, V, H, act)
+    toks = RNG.integers(0, V, size=11)
+    out = torch.zeros((11, H), dtype=dev(np.zeros(1), act).dtype, device="cuda")
+    td = dev_i32(toks)
+    torch.cuda.synchronize()
+    L.check(L.lib().mi_op_embed(C.byref(ol), ptr(td), 11, MIDT[act], 0, ptr(out)))
+    assert np.array_equal(host(out), round_to(wdense[toks], act))
+
+
+def _rope_setup(D, max_pos, base=10000.0, scale=1.0):
+    cos = torch.zeros((max_pos, D // 2), dtype=torch.float32, device="cuda")
+    sin = torch.zeros_like(cos)
+    torch.cuda.synchronize()
+    L.check(L.lib().mi_op_rope_tables(ptr(cos), ptr(sin), max_pos, D, base, scale))
+    c_ref, s_ref = ref_model.rope_tables(D, base, scale, max_pos)
+    assert np.allclose(host(cos), c_ref, atol=1e-7) and np.allclose(host(sin), s_ref, atol=1e-7)
+    return cos, sin, c_ref, s_ref
+
+
+@pytest.mark.parametrize("act", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("Hq,Hkv,D,qk_norm", [(4, 4, 16, False), (8, 2, 64, True), (5, 1, 128, True)])
+@pytest.mark.parametrize("L_", [1, 6])
+def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
+    """q/k norm + RoPE + append, then attention over the cache, prefill (L>1) and decode (L=1, with
+    and without split-KV), heterogeneous per-row offsets."""
+    B, cap, max_pos = 3, 96, 128
+    offs = [17, 0, 40] if L_ == 1 else [5, 0, 9]
+    cos, sin, c_ref, s_ref = _rope_setup(D, max_pos, 1e6 if qk_norm else 1e4)
+    nqkv = (Hq + 2 * Hkv) * D
+    # existing cache contents
+    kc = round_to(RNG.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
+    vc = round_to(RNG.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
+    qkv = round_to(RNG.standard_normal((B, L_, nqkv)).astype(np.float32), act)
+    qn = round_to(1 + 0.1 * RNG.standard_normal(D).astype(np.float32), act)
+    kn = round_to(1 + 0.1 * RNG.standard_normal(D).astype(np.float32), act)
+    # ---- oracle
+    q = qkv[..., :Hq * D].reshape(B, L_, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].reshape(B, L_, Hkv, D)
+    v = qkv[..., (Hq + Hkv) * D:].reshape(B, L_, Hkv, D).transpose(0, 2, 1, 3)
+    if qk_norm:
+        q, _ = ref_model.rms_norm(q, act, qn, act, 1e-6)
+        k, _ = ref_model.rms_norm(k, act, kn, act, 1e-6)
+    pos = np.array([[o + t for t in range(L_)] for o in offs])
+    q = ref_model.rope(q.transpose(0, 2, 1, 3), act, pos, c_ref, s_ref)
+    k = ref_model.rope(k.transpose(0, 2, 1, 3), act, pos, c_ref, s_ref)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    for b in range(B):
+        kc_ref[b, :, offs[b]:offs[b] + L_] = k[b]
+        vc_ref[b, :, offs[b]:offs[b] + L_] = v[b]
+    want = np.zeros((B, L_, Hq * D), np.float32)
+    for b in range(B):
+        n = offs[b] + L_
+        mask = ref_model.create_additive_causal_mask_variable(L_, [offs[b]], n)
+        o, _ = ref_model.sdpa(q[b:b + 1], kc_ref[b:b + 1, :, :n], vc_ref[b:b + 1, :, :n], D ** -0.5, mask, act, act)
+        want[b] = o[0].transpose(1, 0, 2).reshape(L_, Hq * D)
+    # ---- device
+    s = attn_shape(B, L_, Hq, Hkv, D, act, act, 0, cap)
+    qkv_d, kc_d, vc_d = dev(qkv.reshape(B * L_, nqkv), act), dev(kc, act), dev(vc, act)
+    q_d = torch.zeros((B * L_, Hq * D), dtype=qkv_d.dtype, device="cuda")
+    off_d = dev_i32(offs)
+    qn_d, kn_d = dev(qn, act), dev(kn, act)
+    torch.cuda.synchronize()
+    L.check(L.lib().mi_op_rope_append(C.byref(s), ptr(qkv_d), ptr(q_d), ptr(kc_d), ptr(vc_d), ptr(off_d),
+                                      ptr(qn_d) if qk_norm else None, ptr(kn_d) if qk_norm else None, 1e-6,
+                                      ptr(cos), ptr(sin), max_pos))
+    _assert_close(host(q_d).reshape(B, L_, Hq, D).transpose(0, 2, 1, 3), q, act, scale=2.0)
+    _assert_close(host(kc_d), kc_ref, act, scale=2.0)
+    assert np.array_equal(host(vc_d), vc_ref)
+    # attention reads the device's own cache; compare against the oracle with ITS cache
+    for nsplit in ([1] if L_ > 1 else [1, 3]):
+        out = torch.zeros((B * L_, Hq * D), dtype=qkv_d.dtype, device="cuda")
+        part = torch.zeros((B * L_ * Hq * nsplit * (D + 2),), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        L.check(L.lib().mi_op_attention(C.byref(s), ptr(q_d), ptr(kc_d), ptr(vc_d), ptr(off_d), ptr(out),
+                                        float(D ** -0.5), nsplit, ptr(part)))
+        got = host(out).reshape(B, L_, Hq * D)
+        if act == "float32":
+            assert np.allclose(got, want, rtol=1e-4, atol=2e-5), np.abs(got - want).max()
+        else:
+            assert close_frac(got, want, act, atol=1e-3) <= 0.02, close_frac(got, want, act, atol=1e-3)
+
+
+def _run_sampler(lg, temp, top_p, u, k=0):
+    B, V = lg.shape
+    t = dev(lg)
+    ud = dev(np.asarray(u, np.float32))
+    toks = torch.zeros(B, dtype=torch.int32, device="cuda")
+    lp = torch.zeros(B, dtype=torch.float32, device="cuda")
+    p0 = torch.zeros(B, dtype=torch.float32, device="cuda")
+    ki = torch.zeros((B, max(k, 1)), dtype=torch.int32, device="cuda")
+    kl = torch.zeros((B, max(k, 1)), dtype=torch.float32, device="cuda")
+    st = torch.zeros((B, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    L.check(L.lib().mi_op_sample(ptr(t), B, V, temp, top_p, ptr(ud), k, ptr(toks), ptr(lp), ptr(p0), ptr(ki), ptr(kl), ptr(st)))
+    return toks.cpu().numpy(), lp.cpu().numpy(), p0.cpu().numpy(), ki.cpu().numpy(), kl.cpu().numpy()
+
+
+@pytest.mark.parametrize("V", [37, 4096, 151936])
+def test_sampler_greedy_logprobs_topk(V):
+    B = 4
+    lg = RNG.standard_normal((B, V)).astype(np.float32) * 2
+    lg = round_to(lg, "bfloat16")                         # many exact ties, like a bf16 lm_head
+    lg[1, 5] = lg[1].max(); lg[1, 3] = lg[1].max()        # explicit tie: lowest index wins
+    want = ref_sample.sample(lg, temp=0.0)
+    toks, lp, p0, ki, kl = _run_sampler(lg, 0.0, 1.0, np.zeros(B), k=5)
+    assert np.array_equal(toks, want["tokens"][:, 0])
+    assert np.allclose(lp, want["logprobs"], atol=1e-4)
+    assert np.allclose(p0, want["probs"][:, 0], rtol=1e-3, atol=1e-7)
+    lsm = want["log_softmax"]
+    for b in range(B):
+        order = np.lexsort((np.arange(V), -lg[b]))[:5]     # descending logit, ascending id
+        assert np.array_equal(ki[b], order)
+        assert np.allclose(kl[b], lsm[b, order], atol=1e-4)
+
+
+@pytest.mark.parametrize("V", [64, 5000, 151936])
+@pytest.mark.parametrize("temp,top_p", [(1.0, 0.9), (0.7, 0.5), (1.3, 1.0), (1.0, 0.05)])
+def test_sampler_top_p_injected_uniforms(V, temp, top_p):
+    """Same uniforms -> same tokens as the oracle's inverse-CDF pick over the reference's candidate
+    order; and the picked token always lies inside the oracle's nucleus."""
+    B = 8
+    lg = (RNG.standard_normal((B, V)) * 3).astype(np.float32)
+    u = RNG.random(B)
+    want = ref_sample.sample(lg, temp=temp, top_p=top_p, uniforms=u)
+    toks, lp, p0, _, _ = _run_sampler(lg, temp, top_p, u)
+    mism = 0
+    for b in range(B):
+        if top_p < 1.0:
+            ids, pr = ref_sample.top_p_candidates(lg[b], top_p, temp)
+            assert toks[b] in set(ids.tolist())
+        mism += int(toks[b] != want["tokens"][b, 0])
+    assert mism == 0, (toks, want["tokens"][:, 0])
+    assert np.allclose(lp, want["log_softmax"][np.arange(B), toks], atol=1e-4)
