@@ -258,10 +258,11 @@ template <typename AT, typename KT>
 int launch_attn_d(const AttnCall& c, hipStream_t st) {
   switch (c.s.D) {
     case 16: return launch_attn_g<AT, KT, 16>(c, st);
+    case 32: return launch_attn_g<AT, KT, 32>(c, st);
     case 64: return launch_attn_g<AT, KT, 64>(c, st);
     case 128: return launch_attn_g<AT, KT, 128>(c, st);
   }
-  return fail(MI_ERR_UNSUPPORTED, "attention: head_dim must be 16, 64 or 128");
+  return fail(MI_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
 }
 
 }  // namespace

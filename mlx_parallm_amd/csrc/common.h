@@ -59,6 +59,14 @@ __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 template <typename T>
 __device__ __forceinline__ T store_act(float v, int rnd) { return (T)round_rt(v, rnd); }
 
+// scale * q + bias with two roundings (the oracle's `q * scale + bias`); hipcc would otherwise
+// contract it into one FMA (-ffp-contract=fast is the HIP default, and __fmul_rn is a plain `*`).
+__device__ __forceinline__ float mul_add_unfused(float a, float b, float c) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return p + c;
+}
+
 // 16-byte vector of raw bits
 struct alignas(16) u128 { uint32_t x, y, z, w; };
 

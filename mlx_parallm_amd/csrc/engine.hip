@@ -52,6 +52,8 @@ struct FusedLinear {
 struct LayerW {
   FusedLinear qkv, o, gate_up, down;
   void* in_norm = nullptr; void* post_norm = nullptr; void* q_norm = nullptr; void* k_norm = nullptr;
+  // float32 copies for the float32-activation ("PagedKVCache quirk") mode
+  void* in_norm32 = nullptr; void* post_norm32 = nullptr; void* q_norm32 = nullptr; void* k_norm32 = nullptr;
 };
 
 constexpr int NSLOT = 4;
@@ -70,7 +72,7 @@ struct mi_engine {
   hipStream_t stream = nullptr;
   std::vector<LayerW> layers;
   FusedLinear embed, lm_head;
-  void* final_norm = nullptr;
+  void* final_norm = nullptr; void* final_norm32 = nullptr;
   bool finalized = false;
   float* cos_tab = nullptr; float* sin_tab = nullptr;
   // workspace
@@ -187,6 +189,13 @@ int finalize_linear(mi_engine* e, FusedLinear& f, int K, const std::string& name
   f.W.w = f.w; f.W.scales = f.scales; f.W.biases = f.biases;
   f.W.N = total; f.W.K = K; f.W.group = e->d.quant_group_size > 0 ? e->d.quant_group_size : 64;
   return MI_OK;
+}
+
+int make_f32_copy(mi_engine* e, const void* src, int n, void** dst) {
+  if (src == nullptr) { *dst = nullptr; return MI_OK; }
+  if (e->d.act_dtype == MI_F32) { *dst = nullptr; return MI_OK; }
+  MI_HIP(hipMalloc(dst, (size_t)n * sizeof(float)));
+  return launch_convert(src, e->d.act_dtype, *dst, MI_F32, (size_t)n, e->stream);
 }
 
 void free_linear(FusedLinear& f) {
@@ -316,10 +325,15 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
 
   for (int li = 0; li < d.num_layers; ++li) {
     LayerW& lw = e->layers[li];
+    const bool w32 = quirk && d.act_dtype != MI_F32;     // norm weights must match the activation storage type
+    const void* in_norm = w32 ? lw.in_norm32 : lw.in_norm;
+    const void* post_norm = w32 ? lw.post_norm32 : lw.post_norm;
+    const void* q_norm = w32 ? lw.q_norm32 : lw.q_norm;
+    const void* k_norm = w32 ? lw.k_norm32 : lw.k_norm;
     // everything up to the layer-0 attention still rounds to the model dtype in quirk mode
     const int rnd = (quirk && li == 0) ? rndT : RND_NONE;
     {  // input_layernorm + q|k|v projections (llama.py:187,93)
-      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = rnd; c.pro = PRO_NORM; c.norm_w = lw.in_norm;
+      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = rnd; c.pro = PRO_NORM; c.norm_w = in_norm;
       c.eps = d.rms_norm_eps; c.epi = EPI_STORE; c.out = e->qkv; c.ldo = nqkv;
       MI_TRY(gemv_rows(e, lw.qkv, c, R, es, es, "gemv_qkv"));
     }
@@ -327,7 +341,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
     { Prof pr(e, "rope_append");
-      RopeAppendCall rc{s, e->qkv, e->q, kc, vc, kv->d_off, lw.q_norm, lw.k_norm, d.rms_norm_eps,
+      RopeAppendCall rc{s, e->qkv, e->q, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps,
                         e->cos_tab, e->sin_tab, d.max_positions};
       MI_TRY(launch_rope_append(rc, st)); }
     { Prof pr(e, "attn");
@@ -340,7 +354,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
       MI_TRY(gemv_rows(e, lw.o, c, R, es, es, "gemv_o"));
     }
     {  // post_attention_layernorm + gate|up + SwiGLU (llama.py:189,165)
-      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = lw.post_norm;
+      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = post_norm;
       c.eps = d.rms_norm_eps; c.epi = EPI_SWIGLU; c.out = e->act; c.ldo = I; c.pair_offset = I;
       MI_TRY(gemv_rows(e, lw.gate_up, c, R, es, es, "gemv_gate_up"));
     }
@@ -351,7 +365,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
   }
   if (want_logits) {  // final norm + lm_head / tied embedding (llama.py:231,249-252)
     const FusedLinear& head = d.tie_word_embeddings ? e->embed : e->lm_head;
-    GemvCall c; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = e->final_norm; c.eps = d.rms_norm_eps;
+    GemvCall c; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = (quirk && d.act_dtype != MI_F32) ? e->final_norm32 : e->final_norm; c.eps = d.rms_norm_eps;
     c.epi = EPI_STORE_F32; c.out = e->logits; c.ldo = d.vocab_size;
     if (all_pos) { c.x = e->h; c.ldx = H; MI_TRY(gemv_rows(e, head, c, R, es, sizeof(float), "gemv_head")); }
     else { c.x = (char*)e->h + (size_t)(L - 1) * H * es; c.ldx = L * H; MI_TRY(gemv_rows(e, head, c, B, es, sizeof(float), "gemv_head")); }
@@ -451,7 +465,9 @@ void mi_engine_destroy(mi_engine* e) {
   for (auto& l : e->layers) {
     free_linear(l.qkv); free_linear(l.o); free_linear(l.gate_up); free_linear(l.down);
     hipFree(l.in_norm); hipFree(l.post_norm); hipFree(l.q_norm); hipFree(l.k_norm);
+    hipFree(l.in_norm32); hipFree(l.post_norm32); hipFree(l.q_norm32); hipFree(l.k_norm32);
   }
+  hipFree(e->final_norm32);
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t);
@@ -564,10 +580,15 @@ int mi_engine_finalize(mi_engine* e) {
     MI_TRY(finalize_linear(e, l.down, d.intermediate_size, p + ".mlp.down_proj"));
     if (!l.in_norm || !l.post_norm) return fail(MI_ERR_NOTFOUND, p + ": layernorm weights not set");
     if (d.arch == MI_ARCH_QWEN3 && (!l.q_norm || !l.k_norm)) return fail(MI_ERR_NOTFOUND, p + ": q_norm/k_norm not set");
+    MI_TRY(make_f32_copy(e, l.in_norm, H, &l.in_norm32));
+    MI_TRY(make_f32_copy(e, l.post_norm, H, &l.post_norm32));
+    MI_TRY(make_f32_copy(e, l.q_norm, d.head_dim, &l.q_norm32));
+    MI_TRY(make_f32_copy(e, l.k_norm, d.head_dim, &l.k_norm32));
   }
   MI_TRY(finalize_linear(e, e->embed, H, "model.embed_tokens"));
   if (!d.tie_word_embeddings) MI_TRY(finalize_linear(e, e->lm_head, H, "lm_head"));
   if (!e->final_norm) return fail(MI_ERR_NOTFOUND, "model.norm.weight not set");
+  MI_TRY(make_f32_copy(e, e->final_norm, H, &e->final_norm32));
   const size_t n = (size_t)d.max_positions * (d.head_dim / 2);
   MI_HIP(hipMalloc(&e->cos_tab, n * sizeof(float)));
   MI_HIP(hipMalloc(&e->sin_tab, n * sizeof(float)));

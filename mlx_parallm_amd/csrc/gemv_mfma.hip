@@ -54,20 +54,33 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
   }
 }
 
-// int4 code pairs -> 16-bit floats holding (OFFS + q): bf16 0x4300 = 128.0 (ulp 1),
-// f16 0x6400 = 1024.0 (ulp 1); the offset is folded into the per-group bias.
+// int4 code pairs -> 16-bit floats.
+//   bf16: (16 + q) = 2^4 * (1 + q/16): exponent 0x4180, q in mantissa bits 3..6 -- two VALU ops per
+//         pair; the offset 16 is folded into the per-group bias (bias - 16*scale).  (gfx950 has no
+//         packed bf16 add; a larger offset such as 128 costs ~8x more cancellation error.)
+//   f16:  (1024 + q) via 0x6400 | q, then an exact v_pk_add_f16 of -1024 -> q itself, offset 0.
 template <typename T> struct Magic;
-template <> struct Magic<bf16> { static constexpr uint32_t bits = 0x43004300u; static constexpr float offs = 128.f; };
-template <> struct Magic<f16> { static constexpr uint32_t bits = 0x64006400u; static constexpr float offs = 1024.f; };
+template <> struct Magic<bf16> { static constexpr float offs = 16.f; };
+template <> struct Magic<f16> { static constexpr float offs = 0.f; };
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 template <typename T>
 __device__ __forceinline__ u32x4 unpack_q4(uint32_t v) {
   // fragment element 2p <- nibble p, element 2p+1 <- nibble p+4
   u32x4 r;
-  r.x = (v & 0x000F000Fu) | Magic<T>::bits;
-  r.y = ((v >> 4) & 0x000F000Fu) | Magic<T>::bits;
-  r.z = ((v >> 8) & 0x000F000Fu) | Magic<T>::bits;
-  r.w = ((v >> 12) & 0x000F000Fu) | Magic<T>::bits;
+  if constexpr (std::is_same<T, bf16>::value) {
+    r.x = ((v << 3) & 0x00780078u) | 0x41804180u;
+    r.y = ((v >> 1) & 0x00780078u) | 0x41804180u;
+    r.z = ((v >> 5) & 0x00780078u) | 0x41804180u;
+    r.w = ((v >> 9) & 0x00780078u) | 0x41804180u;
+  } else {
+    const f16x2 off = {(_Float16)1024.f, (_Float16)1024.f};
+    r.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, (v & 0x000F000Fu) | 0x64006400u) - off);
+    r.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, ((v >> 4) & 0x000F000Fu) | 0x64006400u) - off);
+    r.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, ((v >> 8) & 0x000F000Fu) | 0x64006400u) - off);
+    r.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, ((v >> 12) & 0x000F000Fu) | 0x64006400u) - off);
+  }
   return r;
 }
 

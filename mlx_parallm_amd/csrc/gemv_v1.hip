@@ -75,14 +75,14 @@ __device__ __forceinline__ void load8(const GemvParams& p, int row, int kb, floa
       const uint32_t* base = (const uint32_t*)p.w + (size_t)row * (p.K / 8) + kb / 8;
       uint32_t v = __builtin_nontemporal_load(base);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = __fadd_rn(__fmul_rn((float)((v >> (4 * j)) & 15u), s), b);
+      for (int j = 0; j < 8; ++j) o[j] = mul_add_unfused((float)((v >> (4 * j)) & 15u), s, b);
     } else {
       const uint32_t* base = (const uint32_t*)p.w + (size_t)row * (p.K / 4) + kb / 4;
       u32x2 v = __builtin_nontemporal_load((const u32x2*)base);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn((float)((v.x >> (8 * j)) & 255u), s), b);
+      for (int j = 0; j < 4; ++j) o[j] = mul_add_unfused((float)((v.x >> (8 * j)) & 255u), s, b);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[4 + j] = __fadd_rn(__fmul_rn((float)((v.y >> (8 * j)) & 255u), s), b);
+      for (int j = 0; j < 4; ++j) o[4 + j] = mul_add_unfused((float)((v.y >> (8 * j)) & 255u), s, b);
     }
   }
 }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void embed_kernel(LinearW W, EmbedCall c) {
       else { s = (float)((const f16*)W.scales)[gi]; b = (float)((const f16*)W.biases)[gi]; }
       const uint32_t word = ((const uint32_t*)W.w)[(size_t)tok * (W.K / PER) + k / PER];
       const float q = (float)((word >> (BITS * (k % PER))) & ((1u << BITS) - 1u));
-      v = __fadd_rn(__fmul_rn(q, s), b);
+      v = mul_add_unfused(q, s, b);
     }
     out[k] = store_act<AT>(v, c.rnd);
   }
