@@ -79,6 +79,8 @@ typedef struct mi_op_attn_shape {
 
 int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a);
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a);
+/* launches the same call `iters` times back to back and returns the mean launch time (HIP events) */
+int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
 int mi_op_embed(const mi_op_linear* w, const int32_t* tokens, int rows, int act, int rnd, void* out);
 int mi_op_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int head_dim, float base, float scale);
 int mi_op_rope_append(const mi_op_attn_shape* s, const void* qkv, void* q_out, void* kcache, void* vcache,

@@ -91,6 +91,7 @@ SIGNATURES = {
     # mi355_ops.h
     "mi_op_gemv": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs)]),
     "mi_op_gemv_uses_mfma": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs)]),
+    "mi_op_gemv_bench": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_float)]),
     "mi_op_embed": (C.c_int, [C.POINTER(OpLinear), _P, C.c_int, C.c_int, C.c_int, _P]),
     "mi_op_rope_tables": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float]),
     "mi_op_rope_append": (C.c_int, [C.POINTER(OpAttnShape), _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int]),

@@ -17,6 +17,7 @@
 // the four waves split K round-robin in 32-wide (dense) or 128-wide (int4) blocks, so that one
 // step of the workgroup reads 256 contiguous bytes of each weight row; partial tiles are
 // summed through LDS.  Activations are staged (RMSNorm applied) as 16-bit MFMA A-fragments.
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels.h"
@@ -25,7 +26,6 @@ namespace mi {
 
 namespace {
 
-constexpr int NTHR = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -101,89 +101,113 @@ __device__ __forceinline__ int frag_slot(int k8, int m, int MB) {
   }
 }
 
-template <typename AT, bool Q4, int MB, bool SWIGLU>
-__global__ __launch_bounds__(NTHR, 2) void gemv_mfma_kernel(MfmaParams p) {
+// Workgroup = NW (= 8) waves, one workgroup per CU (up to 256 VGPRs per lane).  Work is cut into "batches": TB 16-row tiles x a KS-wide slice of K
+// (KS = NW * UK * BK: every wave issues UK 16-byte loads per tile per batch, ALL of them
+// before it touches the activations), so a workgroup has its whole batch -- 128 KiB for a
+// dense bf16 tile at K = 4096 -- in flight at once.  The next batch is issued right after the
+// MFMAs of the current one retire its registers, i.e. before the cross-wave reduction and the
+// epilogue, which keeps HBM busy across tiles of the persistent loop.
+template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
+__global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
+  constexpr int NT = NW * 64;
+  constexpr int NA = SWIGLU ? 2 : 1;
+  constexpr int BK = Q4 ? 128 : 32;      // k covered by one 16-byte load of the 4 lane groups
+  constexpr int UK = Q4 ? (32 / NW) : (128 / NW) / NA;   // loads per wave per tile per weight stream per batch
+  constexpr int TB = Q4 ? 2 : 1;         // tiles per batch
+  constexpr int KS = NW * UK * BK;       // k-span of a batch (4096 dense / 2048 SwiGLU / 4096 int4)
+  // J = staging items per thread per activation row: 1 covers kc <= 8*NT (4096), 2 up to 8192
+  using S = AT;                          // scale dtype == activation dtype on this path
+
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // layout: [frag: kc*MB*2 bytes][sx: (kc/64)*MB floats (int4 only)][red: 4*64*4*(1|2) floats][rs: 16 floats]
+  // layout: [frag: kc*MB*2 B][sx: (kc/64)*MB floats (int4)][red: NW*NA*64 float4][rs: 16][red2: NW*16]
   u32x4* frag = (u32x4*)smem_raw;
   float* sx = (float*)(smem_raw + (size_t)p.kc * MB * 2);
   float* red = sx + (Q4 ? (p.kc / 64) * MB : 0);
-  float* rs_sh = red + 4 * 64 * 4 * (SWIGLU ? 2 : 1);
-  float* red2 = rs_sh + 16;  // [4][16]
+  float* rs_sh = red + NW * NA * 64 * 4;
+  float* red2 = rs_sh + 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const AT* x = (const AT*)p.x;
-  using S = AT;  // scale dtype == activation dtype on this path
+  const int nbatch = (p.ntiles + TB - 1) / TB;
+  const int nchunks = (p.K + p.kc - 1) / p.kc;
+  int tb = blockIdx.x;
+  if (tb >= nbatch) return;
 
-  if (p.pro == PRO_NORM) {
-    float ss[MB];
+  u32x4 wr[NA][TB][UK];
+  uint32_t sr[NA][TB][UK], br[NA][TB][UK];
+  u32x4 xv[MB][J];
+
+  // ---- issue slot u of the weight loads of batch (tbi, [k0, k0+KS) clipped to kend)
+  auto issue_u = [&](int u, int tbi, int k0, int kend) {
+    const int k = k0 + (u * NW + wave) * BK;
+    if (k < kend) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) ss[m] = 0.f;
-    for (int k = tid * 8; k < p.K; k += NTHR * 8) {
+      for (int t = 0; t < TB; ++t) {
+        const int tile = min(tbi * TB + t, p.ntiles - 1);
+        const int row = tile * 16 + c16;
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        if (m < p.M) {
-          const u32x4 v = *(const u32x4*)(x + (size_t)m * p.ldx + k);
-          const AT* e = (const AT*)&v;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float f = (float)e[j]; ss[m] = fmaf(f, f, ss[m]); }
+        for (int a = 0; a < NA; ++a) {
+          const size_t rowa = (size_t)(row + a * p.pair_offset);
+          if constexpr (!Q4) {
+            wr[a][t][u] = __builtin_nontemporal_load((const u32x4*)((const AT*)p.w + rowa * p.K + k + g * 8));
+          } else {
+            wr[a][t][u] = __builtin_nontemporal_load((const u32x4*)((const uint32_t*)p.w + rowa * (p.K / 8) + k / 8 + g * 4));
+            sr[a][t][u] = *(const uint32_t*)((const S*)p.scales + rowa * (p.K / 64) + k / 64);
+            br[a][t][u] = *(const uint32_t*)((const S*)p.biases + rowa * (p.K / 64) + k / 64);
+          }
         }
       }
     }
+  };
+  auto issue_w = [&](int tbi, int k0, int kend) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const float v = wave_sum(ss[m]);
-      if (lane == 0) red2[wave * 16 + m] = v;
-    }
-    __syncthreads();
-    if (tid < MB) {
-      const float v = red2[tid] + red2[16 + tid] + red2[32 + tid] + red2[48 + tid];
-      rs_sh[tid] = 1.0f / sqrtf(v / (float)p.K + p.eps);
-    }
-    __syncthreads();
-  }
+    for (int u = 0; u < UK; ++u) issue_u(u, tbi, k0, kend);
+  };
 
-  const int nchunks = (p.K + p.kc - 1) / p.kc;
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int n0 = tile * 16;
-    const int row0 = n0 + c16;                                   // this lane's weight row
-    const int row1 = SWIGLU ? row0 + p.pair_offset : row0;
+  auto load_x = [&](int kbase, int klen) {
+    const int n8 = klen / 8;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int k8 = tid + j * NT;
+        xv[m][j] = u32x4{0u, 0u, 0u, 0u};
+        if (m < p.M && k8 < n8) xv[m][j] = *(const u32x4*)(x + (size_t)m * p.ldx + kbase + k8 * 8);
+      }
+  };
 
-    for (int c = 0; c < nchunks; ++c) {
-      const int kbase = c * p.kc;
-      const int klen = min(p.kc, p.K - kbase);
-      if (nchunks > 1 || tile == (int)blockIdx.x) {
-        __syncthreads();
-        // ---- stage x[:, kbase : kbase+klen] as MFMA A-fragments
-        const int n8 = klen / 8;
-        for (int idx = tid; idx < MB * n8; idx += NTHR) {
-          const int m = idx / n8, k8 = idx % n8, k = kbase + k8 * 8;
-          u32x4 v = {0u, 0u, 0u, 0u};
+  // xv -> (RMSNorm) -> MFMA A-fragments in LDS
+  auto stage_x = [&](int kbase, int klen) {
+    const int n8 = klen / 8;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int k8 = tid + j * NT;
+        if (k8 < n8) {
+          u32x4 v = xv[m][j];
+          AT* e = (AT*)&v;
           float sum = 0.f;
           if (m < p.M) {
-            v = *(const u32x4*)(x + (size_t)m * p.ldx + k);
-            AT* e = (AT*)&v;
             if (p.pro == PRO_NORM) {
-              const u32x4 wv = *(const u32x4*)((const AT*)p.norm_w + k);
+              const u32x4 wv = *(const u32x4*)((const AT*)p.norm_w + kbase + k8 * 8);
               const AT* we = (const AT*)&wv;
               const float rs = rs_sh[m];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const AT xn = (AT)((float)e[j] * rs);              // cast_T(x32 * rsqrt(..))
-                e[j] = (AT)((float)xn * (float)we[j]);            // w * (.)  in T
+              for (int i = 0; i < 8; ++i) {
+                const AT xn = (AT)((float)e[i] * rs);              // cast_T(x32 * rsqrt(..))
+                e[i] = (AT)((float)xn * (float)we[i]);            // w * (.)  in T
               }
             }
             if constexpr (Q4) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) sum += (float)e[j];
-              // nibble order: element 2p <- k+p, element 2p+1 <- k+p+4
-              AT t[8];
+              for (int i = 0; i < 8; ++i) sum += (float)e[i];
+              AT t2[8];                                            // nibble order: 2q <- k+q, 2q+1 <- k+q+4
 #pragma unroll
-              for (int q = 0; q < 4; ++q) { t[2 * q] = e[q]; t[2 * q + 1] = e[q + 4]; }
+              for (int q = 0; q < 4; ++q) { t2[2 * q] = e[q]; t2[2 * q + 1] = e[q + 4]; }
 #pragma unroll
-              for (int j = 0; j < 8; ++j) e[j] = t[j];
+              for (int i = 0; i < 8; ++i) e[i] = t2[i];
             }
           }
           frag[frag_slot<Q4>(k8, m, MB)] = v;
@@ -195,185 +219,252 @@ __global__ __launch_bounds__(NTHR, 2) void gemv_mfma_kernel(MfmaParams p) {
             if ((k8 & 7) == 0) sx[(k8 >> 3) * MB + m] = sum;
           }
         }
-        __syncthreads();
       }
+  };
 
-      if constexpr (!Q4) {
-        // ---- dense: this wave takes 32-wide k-blocks wave, wave+4, ...
-        const int nkb = klen / 32;
-        const AT* w0 = (const AT*)p.w + (size_t)row0 * p.K + kbase + g * 8;
-        const AT* w1 = (const AT*)p.w + (size_t)row1 * p.K + kbase + g * 8;
-        constexpr int U = 8;
-        for (int kb0 = wave; kb0 < nkb; kb0 += 4 * U) {
-          u32x4 b0[U], b1[U];
+  f32x4 acc[NA][TB];
+  auto zero_acc = [&]() {
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int kb = kb0 + 4 * u;
-            if (kb < nkb) {
-              b0[u] = __builtin_nontemporal_load((const u32x4*)(w0 + kb * 32));
-              if constexpr (SWIGLU) b1[u] = __builtin_nontemporal_load((const u32x4*)(w1 + kb * 32));
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int t = 0; t < TB; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- MFMAs of slot u of batch [k0, k0+KS) clipped to kend; fragments are addressed relative to cbase
+  auto mfma_u = [&](int u, int k0, int kend, int cbase) {
+    {
+      const int k = k0 + (u * NW + wave) * BK;
+      if (k < kend) {
+        const int kb = (k - cbase) / BK;
+        if constexpr (!Q4) {
+          u32x4 af = {0u, 0u, 0u, 0u};
+          if (MB == 16 || c16 < MB) af = frag[(kb * 4 + g) * MB + c16];
+#pragma unroll
+          for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[a][t] = mfma16<AT>(af, wr[a][t][u], acc[a][t]);
+        } else {
+          u32x4 af[2][2];
+          f32x4 sxv[2];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+              af[s][t2] = u32x4{0u, 0u, 0u, 0u};
+              if (MB == 16 || c16 < MB) af[s][t2] = frag[((((kb * 2 + s) * 2 + t2) * 4 + g) * MB + c16)];
             }
+            sxv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (MB == 16 || g * 4 < MB) sxv[s] = *(const f32x4*)&sx[(kb * 2 + s) * MB + g * 4];
           }
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int kb = kb0 + 4 * u;
-            if (kb < nkb) {
-              u32x4 a = {0u, 0u, 0u, 0u};
-              if (MB == 16 || c16 < MB) a = frag[(kb * 4 + g) * MB + c16];
-              acc0 = mfma16<AT>(a, b0[u], acc0);
-              if constexpr (SWIGLU) acc1 = mfma16<AT>(a, b1[u], acc1);
-            }
-          }
-        }
-      } else {
-        // ---- int4 (group 64): this wave takes 128-wide k-blocks wave, wave+4, ...
-        const int nkb = klen / 128;
-        const int ng = p.K / 64;
-        const uint32_t* w0 = (const uint32_t*)p.w + (size_t)row0 * (p.K / 8) + kbase / 8 + g * 4;
-        const uint32_t* w1 = (const uint32_t*)p.w + (size_t)row1 * (p.K / 8) + kbase / 8 + g * 4;
-        const S* sc0 = (const S*)p.scales + (size_t)row0 * ng + kbase / 64;
-        const S* bi0 = (const S*)p.biases + (size_t)row0 * ng + kbase / 64;
-        const S* sc1 = (const S*)p.scales + (size_t)row1 * ng + kbase / 64;
-        const S* bi1 = (const S*)p.biases + (size_t)row1 * ng + kbase / 64;
-        constexpr int U = 4;
-        for (int kb0 = wave; kb0 < nkb; kb0 += 4 * U) {
-          u32x4 q0[U], q1[U];
+          for (int t = 0; t < TB; ++t)
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int kb = kb0 + 4 * u;
-            if (kb < nkb) {
-              q0[u] = __builtin_nontemporal_load((const u32x4*)(w0 + kb * 16));
-              if constexpr (SWIGLU) q1[u] = __builtin_nontemporal_load((const u32x4*)(w1 + kb * 16));
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int kb = kb0 + 4 * u;
-            if (kb < nkb) {
-              // lanes g<2 hold quant group A (dwords 0-7 of the 128 block), g>=2 group B.  Swap
-              // the upper half's {x,y} with the lower half's {z,w}: afterwards {x,y} = group A
-              // and {z,w} = group B in EVERY lane (v_permlane32_swap).
-              u32x4 v = q0[u];
-              {
-                auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
-                v.x = r0[0]; v.z = r0[1]; v.y = r1[0]; v.w = r1[1];
-              }
-              u32x4 vv = v;
-              if constexpr (SWIGLU) {
-                vv = q1[u];
-                auto r0 = __builtin_amdgcn_permlane32_swap(vv.x, vv.z, false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(vv.y, vv.w, false, false);
-                vv.x = r0[0]; vv.z = r0[1]; vv.y = r1[0]; vv.w = r1[1];
-              }
-              const uint32_t dw0[4] = {v.x, v.y, v.z, v.w};
-              const uint32_t dw1[4] = {vv.x, vv.y, vv.z, vv.w};
+            for (int a = 0; a < NA; ++a) {
+              // lanes g<2 hold quant group A (dwords 0-7 of the 128 block), g>=2 group B.  Swap the
+              // upper half's {x,y} with the lower half's {z,w}: afterwards {x,y} = group A and
+              // {z,w} = group B in EVERY lane (v_permlane32_swap).
+              u32x4 v = wr[a][t][u];
+              auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+              auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+              const uint32_t dw[4] = {r0[0], r1[0], r0[1], r1[1]};
+              const S* sp = (const S*)&sr[a][t][u];
+              const S* bp = (const S*)&br[a][t][u];
 #pragma unroll
               for (int s = 0; s < 2; ++s) {
-                const int gi = kb * 2 + s;
-                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                  u32x4 a = {0u, 0u, 0u, 0u};
-                  if (MB == 16 || c16 < MB) a = frag[((((kb * 2 + s) * 2 + t) * 4 + g) * MB + c16)];
-                  d0 = mfma16<AT>(a, unpack_q4<AT>(dw0[s * 2 + t]), d0);
-                  if constexpr (SWIGLU) d1 = mfma16<AT>(a, unpack_q4<AT>(dw1[s * 2 + t]), d1);
-                }
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                d = mfma16<AT>(af[s][0], unpack_q4<AT>(dw[s * 2 + 0]), d);
+                d = mfma16<AT>(af[s][1], unpack_q4<AT>(dw[s * 2 + 1]), d);
                 // y += scale * sum((OFFS+q) x) + (bias - OFFS*scale) * sum(x)   per output row m
-                const float s0 = (float)sc0[gi], bb0 = (float)bi0[gi] - Magic<AT>::offs * s0;
-                f32x4 sxv = {0.f, 0.f, 0.f, 0.f};
-                if (MB == 16 || g * 4 < MB) sxv = *(const f32x4*)&sx[gi * MB + g * 4];
-                acc0.x = fmaf(s0, d0.x, fmaf(bb0, sxv.x, acc0.x));
-                acc0.y = fmaf(s0, d0.y, fmaf(bb0, sxv.y, acc0.y));
-                acc0.z = fmaf(s0, d0.z, fmaf(bb0, sxv.z, acc0.z));
-                acc0.w = fmaf(s0, d0.w, fmaf(bb0, sxv.w, acc0.w));
-                if constexpr (SWIGLU) {
-                  const float s1 = (float)sc1[gi], bb1 = (float)bi1[gi] - Magic<AT>::offs * s1;
-                  acc1.x = fmaf(s1, d1.x, fmaf(bb1, sxv.x, acc1.x));
-                  acc1.y = fmaf(s1, d1.y, fmaf(bb1, sxv.y, acc1.y));
-                  acc1.z = fmaf(s1, d1.z, fmaf(bb1, sxv.z, acc1.z));
-                  acc1.w = fmaf(s1, d1.w, fmaf(bb1, sxv.w, acc1.w));
+                const float sc = (float)sp[s], bb = (float)bp[s] - Magic<AT>::offs * sc;
+                acc[a][t].x = fmaf(sc, d.x, fmaf(bb, sxv[s].x, acc[a][t].x));
+                acc[a][t].y = fmaf(sc, d.y, fmaf(bb, sxv[s].y, acc[a][t].y));
+                acc[a][t].z = fmaf(sc, d.z, fmaf(bb, sxv[s].z, acc[a][t].z));
+                acc[a][t].w = fmaf(sc, d.w, fmaf(bb, sxv[s].w, acc[a][t].w));
+              }
+            }
+        }
+      }
+    }
+  };
+
+  // ---- cross-wave reduction + epilogue of the TB tiles of batch tbi
+  auto finish = [&](int tbi) {
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const int tile = tbi * TB + t;
+      if (tile >= p.ntiles) break;                 // uniform
+      if (t > 0) __syncthreads();
+#pragma unroll
+      for (int a = 0; a < NA; ++a) *(f32x4*)&red[((wave * NA + a) * 64 + lane) * 4] = acc[a][t];
+      __syncthreads();
+      if (tid < 256) {
+        const int el = tid & 63, r = tid >> 6;
+        const int m = 4 * (el >> 4) + r, n = tile * 16 + (el & 15);
+        float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          y0 += red[((w * NA + 0) * 64 + el) * 4 + r];
+          if constexpr (SWIGLU) y1 += red[((w * NA + 1) * 64 + el) * 4 + r];
+        }
+        if (m < p.M && n < p.N) {
+          AT* out = (AT*)p.out;
+          if constexpr (SWIGLU) {
+            const float gt = (float)(AT)y0, up = (float)(AT)y1;
+            const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+            const float sl = (float)(AT)(gt * sig);
+            out[(size_t)m * p.ldo + n] = (AT)(sl * up);
+          } else {
+            float y = (float)(AT)y0;
+            if (p.lora_t != nullptr) {
+#pragma unroll
+              for (int sl = 0; sl < 2; ++sl) {
+                const int r0 = sl ? p.lora_row0_1 : p.lora_row0_0;
+                const int ln = sl ? p.lora_n_1 : p.lora_n_0;
+                const int rk = sl ? p.lora_rank_1 : p.lora_rank_0;
+                const float* lb = sl ? p.lora_b1 : p.lora_b0;
+                if (lb != nullptr && n >= r0 && n < r0 + ln) {
+                  const float* tt = p.lora_t + (size_t)m * p.lora_t_ld + sl * (p.lora_t_ld / 2);
+                  float z = 0.f;
+                  for (int j = 0; j < rk; ++j) z = fmaf(tt[j], lb[(size_t)j * ln + (n - r0)], z);
+                  z = (sl ? p.lora_scale_1 : p.lora_scale_0) * z;
+                  y = (float)(AT)(y + (float)(AT)z);
                 }
               }
             }
-          }
-        }
-      }
-    }
-
-    // ---- sum the four waves' partial tiles through LDS; thread (lane, r) finishes y[4g+r][n0+c16]
-    constexpr int NA = SWIGLU ? 2 : 1;
-    *(f32x4*)&red[((wave * NA + 0) * 64 + lane) * 4] = acc0;
-    if constexpr (SWIGLU) *(f32x4*)&red[((wave * NA + 1) * 64 + lane) * 4] = acc1;
-    __syncthreads();
-    {
-      const int el = tid & 63, r = tid >> 6;
-      const int m = 4 * (el >> 4) + r, n = n0 + (el & 15);
-      float y0 = 0.f, y1 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        y0 += red[((w * NA + 0) * 64 + el) * 4 + r];
-        if constexpr (SWIGLU) y1 += red[((w * NA + 1) * 64 + el) * 4 + r];
-      }
-      if (m < p.M && n < p.N) {
-        AT* out = (AT*)p.out;
-        if constexpr (SWIGLU) {
-          const float gt = (float)(AT)y0, up = (float)(AT)y1;
-          const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
-          const float sl = (float)(AT)(gt * sig);
-          out[(size_t)m * p.ldo + n] = (AT)(sl * up);
-        } else {
-          float y = (float)(AT)y0;
-          if (p.lora_t != nullptr) {
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-              const int r0 = sl ? p.lora_row0_1 : p.lora_row0_0;
-              const int ln = sl ? p.lora_n_1 : p.lora_n_0;
-              const int rk = sl ? p.lora_rank_1 : p.lora_rank_0;
-              const float* lb = sl ? p.lora_b1 : p.lora_b0;
-              if (lb != nullptr && n >= r0 && n < r0 + ln) {
-                const float* t = p.lora_t + (size_t)m * p.lora_t_ld + sl * (p.lora_t_ld / 2);
-                float z = 0.f;
-                for (int j = 0; j < rk; ++j) z = fmaf(t[j], lb[(size_t)j * ln + (n - r0)], z);
-                z = (sl ? p.lora_scale_1 : p.lora_scale_0) * z;
-                y = (float)(AT)(y + (float)(AT)z);
-              }
+            if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
+            else if (p.epi == EPI_STORE_F32) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
+            else {
+              AT* h = (AT*)p.resid;
+              h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
             }
           }
-          if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
-          else if (p.epi == EPI_STORE_F32) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
-          else {
-            AT* h = (AT*)p.resid;
-            h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+        }
+      }
+    }
+  };
+
+  // ================= prologue: activations first (older in the vmcnt queue), then weights
+  const int klen0 = min(p.kc, p.K);
+  load_x(0, klen0);
+  issue_w(tb, 0, klen0);
+  if (p.pro == PRO_NORM) {
+    float ss[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) ss[m] = 0.f;
+    if (nchunks == 1) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const AT* e = (const AT*)&xv[m][j];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float f = (float)e[i]; ss[m] = fmaf(f, f, ss[m]); }
+        }
+    } else {
+      for (int k = tid * 8; k < p.K; k += NT * 8) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          if (m < p.M) {
+            const u32x4 v = *(const u32x4*)(x + (size_t)m * p.ldx + k);
+            const AT* e = (const AT*)&v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float f = (float)e[i]; ss[m] = fmaf(f, f, ss[m]); }
           }
         }
       }
     }
-    __syncthreads();  // `red` is reused by the next tile
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float v = wave_sum(ss[m]);
+      if (lane == 0) red2[wave * 16 + m] = v;
+    }
+    __syncthreads();
+    if (tid < MB) {
+      float v = 0.f;
+      for (int w = 0; w < NW; ++w) v += red2[w * 16 + tid];
+      rs_sh[tid] = 1.0f / sqrtf(v / (float)p.K + p.eps);
+    }
+    __syncthreads();
+  }
+  stage_x(0, klen0);
+  __syncthreads();
+  int staged = 0;
+
+  // ================= persistent loop over tile batches
+  for (; tb < nbatch; tb += gridDim.x) {
+    zero_acc();
+    for (int c = 0; c < nchunks; ++c) {
+      const int cbase = c * p.kc, kend = min(p.K, cbase + p.kc);
+      if (staged != c) {
+        load_x(cbase, kend - cbase);
+        __syncthreads();                      // every wave is done reading the old fragments
+        stage_x(cbase, kend - cbase);
+        __syncthreads();
+        staged = c;
+      }
+      for (int k0 = cbase; k0 < kend; k0 += KS) {
+        // the batch that follows this one in this workgroup's sequence
+        int ntb = tb, nk0 = k0 + KS, nkend = kend;
+        if (nk0 >= kend) {
+          if (c + 1 < nchunks) { nk0 = cbase + p.kc; nkend = min(p.K, cbase + 2 * p.kc); }
+          else if (tb + (int)gridDim.x < nbatch) { ntb = tb + gridDim.x; nk0 = 0; nkend = klen0; }
+          else { nk0 = 0; nkend = 0; }                         // nothing left: issue_u becomes a no-op
+        }
+        // rolling prefetch: as soon as the MFMAs of slot u have consumed its registers, the same
+        // registers are re-loaded with slot u of the NEXT batch, so every wave keeps UK loads in
+        // flight at all times.  The scheduling barriers pin this order (hoisting the loads would
+        // double the register footprint, sinking them would drain the memory pipe).
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+          mfma_u(u, k0, kend, cbase);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_u(u, ntb, nk0, nkend);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    finish(tb);
+    __syncthreads();                          // `red` / fragments are reused
   }
 }
 
-template <typename AT, bool Q4, int MB, bool SWIGLU>
-int launch_one(const MfmaParams& p, int nwg, hipStream_t st) {
-  auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU>;
+template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
+int launch_j(const MfmaParams& p, hipStream_t st) {
+  auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU, NW, J>;
+  constexpr int NA = SWIGLU ? 2 : 1;
+  constexpr int TB = Q4 ? 2 : 1;
   const size_t lds = (size_t)p.kc * MB * 2 + (Q4 ? (size_t)(p.kc / 64) * MB * 4 : 0) +
-                     (size_t)4 * 64 * 4 * (SWIGLU ? 2 : 1) * 4 + 16 * 4 + 64 * 4;
+                     (size_t)NW * NA * 64 * 4 * 4 + 16 * 4 + (size_t)NW * 16 * 4;
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHR), lds, st, p);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int nbatch = (p.ntiles + TB - 1) / TB;
+  const int nwg = std::min(nbatch, n_cu);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, p);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
 
+template <typename AT, bool Q4, int MB, bool SWIGLU, int NW>
+int launch_one(const MfmaParams& p, hipStream_t st) {
+  if (p.kc <= 8 * NW * 64) return launch_j<AT, Q4, MB, SWIGLU, NW, 1>(p, st);
+  return launch_j<AT, Q4, MB, SWIGLU, NW, 2>(p, st);
+}
+
 template <typename AT>
-int launch_at(bool q4, const MfmaParams& p, int nwg, hipStream_t st) {
+int launch_at(bool q4, const MfmaParams& p, hipStream_t st) {
   const bool sw = p.epi == EPI_SWIGLU;
   const bool m8 = p.M <= 8;
   if (!q4) {
-    if (m8) return sw ? launch_one<AT, false, 8, true>(p, nwg, st) : launch_one<AT, false, 8, false>(p, nwg, st);
-    return sw ? launch_one<AT, false, 16, true>(p, nwg, st) : launch_one<AT, false, 16, false>(p, nwg, st);
+    if (m8) return sw ? launch_one<AT, false, 8, true, 8>(p, st) : launch_one<AT, false, 8, false, 8>(p, st);
+    return sw ? launch_one<AT, false, 16, true, 8>(p, st) : launch_one<AT, false, 16, false, 8>(p, st);
   }
-  if (m8) return sw ? launch_one<AT, true, 8, true>(p, nwg, st) : launch_one<AT, true, 8, false>(p, nwg, st);
-  return sw ? launch_one<AT, true, 16, true>(p, nwg, st) : launch_one<AT, true, 16, false>(p, nwg, st);
+  if (m8) return sw ? launch_one<AT, true, 8, true, 8>(p, st) : launch_one<AT, true, 8, false, 8>(p, st);
+  return sw ? launch_one<AT, true, 16, true, 8>(p, st) : launch_one<AT, true, 16, false, 8>(p, st);
 }
 
 }  // namespace
@@ -402,17 +493,16 @@ int launch_gemv_mfma(const LinearW& W, const GemvCall& c, hipStream_t st) {
   p.w = W.w; p.scales = W.scales; p.biases = W.biases; p.N = (c.epi == EPI_SWIGLU) ? c.pair_offset : W.N; p.K = W.K;
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
   p.ntiles = p.N / 16;
-  const int MB = c.M <= 8 ? 8 : 16;
-  // K chunk: whole K when the fragments fit in 64 KiB (two workgroups per CU), else 4096/2048
-  const int kc_max = (64 * 1024) / (MB * 2);
-  p.kc = (W.K <= kc_max) ? W.K : kc_max;
+  // activation chunk held in LDS as fragments: whole K up to 6144 (M <= 8) / 4096 (M <= 16),
+  // else chunks of 4096 (a multiple of every batch span and of the int4 block)
+  const int kc_max = c.M <= 8 ? 6144 : 4096;
+  p.kc = (W.K <= kc_max) ? W.K : 4096;
   p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;
   p.lora_b0 = W.lora_b[0]; p.lora_b1 = W.lora_b[1];
   p.lora_row0_0 = W.lora_row0[0]; p.lora_n_0 = W.lora_n[0]; p.lora_rank_0 = W.lora_rank[0]; p.lora_scale_0 = W.lora_scale[0];
   p.lora_row0_1 = W.lora_row0[1]; p.lora_n_1 = W.lora_n[1]; p.lora_rank_1 = W.lora_rank[1]; p.lora_scale_1 = W.lora_scale[1];
-  const int nwg = p.ntiles;
-  if (c.act == MI_BF16) return launch_at<bf16>(q4, p, nwg, st);
-  return launch_at<f16>(q4, p, nwg, st);
+  if (c.act == MI_BF16) return launch_at<bf16>(q4, p, st);
+  return launch_at<f16>(q4, p, st);
 }
 
 }  // namespace mi

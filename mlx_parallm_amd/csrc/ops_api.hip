@@ -58,6 +58,25 @@ int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a) {
   return finish();
 }
 
+int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms) {
+  if (!w || !a || !avg_ms || iters < 1) return fail(MI_ERR_INVALID, "bad argument");
+  MI_TRY(ready());
+  const LinearW W = to_linear(w);
+  const GemvCall c = to_call(a);
+  hipEvent_t e0, e1;
+  MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));
+  MI_TRY(launch_gemv(W, c, nullptr));                   // warm-up
+  MI_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) MI_TRY(launch_gemv(W, c, nullptr));
+  MI_HIP(hipEventRecord(e1, nullptr));
+  MI_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MI_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = ms / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return finish();
+}
+
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a) {
   if (!w || !a) return 0;
   return gemv_mfma_supported(to_linear(w), to_call(a)) ? 1 : 0;
