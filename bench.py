@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-timing", action="store_true")
     ap.add_argument("--profile-kernel", default="gemv_gate_up")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (A/B experiments)")
     args = ap.parse_args()
 
     import numpy as np
@@ -161,6 +162,9 @@ def main():
     B, ctx, K, W = args.batch, args.context, args.steps, args.warmup
     cap = ctx + 2 * (K + W) + 8
     engine = Engine(cfg, device=local_rank, max_positions=max(cap, 2048), act_dtype="bfloat16")
+    for kv_ in args.opt:
+        k_, v_ = kv_.split("=")
+        engine.set_option(k_, int(v_))
     t0 = time.perf_counter()
     load_synthetic(engine, cfg, args.seed, quant_bits, rank, world, dist)
     t_load = time.perf_counter() - t0

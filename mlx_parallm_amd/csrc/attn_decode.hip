@@ -1,0 +1,394 @@
+// attn_decode.hip -- fused decode step of one attention block (L == 1), ONE launch:
+//   q/k RMSNorm (qwen3.py:65-70) + RoPE (llama.py:107-117) + KV append (base.py:66-85 / 119-140)
+//   + scaled_dot_product_attention over the cache (llama.py:139-141) + split-KV combine.
+//
+// Grid (nsplit, B*Hkv), 512 threads = 8 waves.  A lane group of 16 lanes (one DPP row) owns one
+// key at a time and D/16 elements of it: a wave reads four consecutive KV rows (1 KiB for
+// bf16 D = 128) per instruction, and every (wave, lane group) issues U K-rows and U V-rows before
+// touching any of them, so a 256-key split is entirely in flight at once.
+//   * the GQA group (G = Hq/Hkv query heads) shares every K/V row;
+//   * q.k on 16-bit caches uses v_dot2c_f32_{bf16,f16}; the 16-lane reductions are DPP row
+//     rotations (no LDS traffic); softmax runs in the exp2 domain, one rescale per U-key block;
+//   * the RoPE partner (i <-> i + D/2) is the lane 8 positions away in the row;
+//   * the split that owns the new position appends K/V and takes the new key from registers;
+//   * splits publish (max, sum, O) partials and take a ticket; the last arriver of a
+//     (sequence, kv-head) combines them (agent-scope release -> ticket -> acquire; nobody waits).
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace mi {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// all-reduce over the 16 lanes of a DPP row (row_ror:8,4,2,1)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x128, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x124, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x122, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x121, 0xf, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ float row16_ror8(float v) { return __builtin_amdgcn_update_dpp(0.f, v, 0x128, 0xf, 0xf, false); }
+
+template <typename T>
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+  if constexpr (std::is_same<T, bf16>::value)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+  else
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+}
+
+// one lane's piece of a row: NW32 dwords of raw bits
+template <int NW32>
+__device__ __forceinline__ void load_raw(const void* p, uint32_t (&o)[NW32]) {
+  if constexpr (NW32 % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < NW32 / 4; ++i) {
+      const u32x4 v = *((const u32x4*)p + i);
+      o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w;
+    }
+  } else if constexpr (NW32 == 2) {
+    const u32x2 v = *(const u32x2*)p;
+    o[0] = v.x; o[1] = v.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NW32; ++i) o[i] = ((const uint32_t*)p)[i];
+  }
+}
+
+template <typename T, int EPL, int NW32>
+__device__ __forceinline__ void raw_to_f32(const uint32_t (&r)[NW32], float (&o)[EPL]) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = __uint_as_float(r[e]);
+  } else if constexpr (std::is_same<T, bf16>::value) {
+#pragma unroll
+    for (int e = 0; e < EPL / 2; ++e) { o[2 * e] = __uint_as_float(r[e] << 16); o[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPL / 2; ++e) {
+      const f16x2 h = __builtin_bit_cast(f16x2, r[e]);
+      o[2 * e] = (float)h.x; o[2 * e + 1] = (float)h.y;
+    }
+  }
+}
+
+// D must be a multiple of 32 for 16-bit caches (two elements per dword per lane); float caches any D % 16 == 0
+template <typename T, int D, int G>
+__global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
+  constexpr int EPL = D / 16, NWV = 8, U = 8;
+  constexpr int NW32 = EPL * (int)sizeof(T) / 4;
+  constexpr bool PACKED = sizeof(T) == 2;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const AttnShape& s = c.s;
+  const int split = blockIdx.x, bh = blockIdx.y;
+  const int b = bh / s.Hkv, kh = bh % s.Hkv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, gq = lane >> 4;
+  const int pos = c.offsets[b];
+  const int n_keys = pos + 1;
+  const int chunk = (n_keys + c.nsplit - 1) / c.nsplit;
+  const int s0 = split * chunk, s1 = min(n_keys, s0 + chunk);
+  const bool owner = pos >= s0 && pos < s1;
+  const int nq = s.Hq * D;
+  const T* row = (const T*)c.qkv + (size_t)b * (nq + 2 * s.Hkv * D);
+
+  __shared__ float st_m[NWV][G], st_l[NWV][G];
+  __shared__ float st_o[NWV][G][D];
+  __shared__ int is_last_sh;
+
+  // ---- the K/V rows of the first block go out before anything else: they depend on nothing
+  // but the offsets, and their latency then hides the q / k_new prologue
+  T* kc = (T*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+  T* vc = (T*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+  const int send = min(s1, pos);                 // cached keys of this split: [s0, send)
+  const T* kbase = kc + li * EPL;
+  const T* vbase = vc + li * EPL;
+  uint32_t kr[U][NW32], vr[U][NW32];
+  bool ok[U];
+  auto issue_kv = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sp = base + 4 * wave + gq + 4 * NWV * u;
+      ok[u] = sp < send;
+      const int spc = ok[u] ? sp : s0;
+      load_raw<NW32>(kbase + (size_t)spc * D, kr[u]);
+      load_raw<NW32>(vbase + (size_t)spc * D, vr[u]);
+    }
+  };
+  if (s0 < send) issue_kv(s0);
+
+  // ---- prologue: this lane's pieces of q (G heads), k_new, v_new; norm + RoPE in registers
+  const bool hi = li >= 8;                       // this lane holds the second half of a RoPE pair
+  float cs[EPL], sn[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int i = (li & 7) * EPL + e;
+    cs[e] = c.cos_tab[(size_t)pos * (D / 2) + i];
+    sn[e] = c.sin_tab[(size_t)pos * (D / 2) + i];
+  }
+  auto load_piece = [&](const T* p, float (&x)[EPL]) {
+    uint32_t r[NW32];
+    load_raw<NW32>(p, r);
+    raw_to_f32<T, EPL, NW32>(r, x);
+  };
+  auto norm_rope = [&](float (&x)[EPL], const T* nw) {
+    if (nw != nullptr) {
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) ss = fmaf(x[e], x[e], ss);
+      ss = row16_sum(ss);
+      const float rs = 1.0f / sqrtf(ss / (float)D + c.eps);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        x[e] = to_f32(store_act<T>(to_f32(store_act<T>(x[e] * rs, s.rnd)) * (float)nw[li * EPL + e], s.rnd));
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const float p = row16_ror8(x[e]);          // the partner lane (li ^ 8) of the same row
+      const float o = hi ? (p * sn[e] + x[e] * cs[e]) : (x[e] * cs[e] - p * sn[e]);
+      x[e] = to_f32(store_act<T>(o, s.rnd));
+    }
+  };
+  auto pack = [&](const float (&x)[EPL], uint32_t (&r)[NW32]) {
+    if constexpr (PACKED) {
+#pragma unroll
+      for (int e = 0; e < EPL / 2; ++e) {
+        T a[2] = {(T)x[2 * e], (T)x[2 * e + 1]};
+        r[e] = __builtin_bit_cast(uint32_t, a);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) r[e] = __float_as_uint(x[e]);
+    }
+  };
+
+  uint32_t qr[G][NW32];                          // q after norm + RoPE, in the cache's element type
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float x[EPL];
+    load_piece(row + (size_t)(kh * G + g) * D + li * EPL, x);
+    norm_rope(x, (const T*)c.q_norm_w);
+    pack(x, qr[g]);
+  }
+  uint32_t knr[NW32], vnr[NW32];
+  {
+    float x[EPL];
+    load_piece(row + nq + (size_t)kh * D + li * EPL, x);
+    norm_rope(x, (const T*)c.k_norm_w);
+    pack(x, knr);
+    load_raw<NW32>(row + nq + (size_t)(s.Hkv + kh) * D + li * EPL, vnr);
+  }
+  if (owner && wave == 0 && gq == 0 && pos < s.cap) {
+#pragma unroll
+    for (int i = 0; i < NW32; ++i) {
+      ((uint32_t*)(kc + (size_t)pos * D + li * EPL))[i] = knr[i];
+      ((uint32_t*)(vc + (size_t)pos * D + li * EPL))[i] = vnr[i];
+    }
+  }
+
+  // ---- streaming softmax state (exp2 domain; finite "minus infinity" keeps every exp2 argument finite)
+  const float sc2 = c.scale * LOG2E;
+  float m[G], l[G], o[G][EPL];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = -1e30f; l[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
+  }
+  auto score = [&](const uint32_t (&kr)[NW32], int g) -> float {
+    float d = 0.f;
+    if constexpr (PACKED) {
+#pragma unroll
+      for (int i = 0; i < NW32; ++i) d = dot2<T>(kr[i], qr[g][i], d);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NW32; ++i) d = fmaf(__uint_as_float(kr[i]), __uint_as_float(qr[g][i]), d);
+    }
+    return d;
+  };
+  // NK keys held by this lane group: scores -> one rescale -> P.V
+  auto block = [&](auto& kr, auto& vr, const bool* ok, auto nk_tag) {
+    constexpr int NK = decltype(nk_tag)::value;
+    float d[NK][G];
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+#pragma unroll
+      for (int g = 0; g < G; ++g) d[u][g] = score(kr[u], g);
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float v = row16_sum(d[u][g]) * sc2;
+        d[u][g] = ok[u] ? v : -INFINITY;
+      }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float mn = m[g];
+#pragma unroll
+      for (int u = 0; u < NK; ++u) mn = fmaxf(mn, d[u][g]);
+      const float corr = __builtin_amdgcn_exp2f(m[g] - mn);
+      l[g] *= corr;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[g][e] *= corr;
+#pragma unroll
+      for (int u = 0; u < NK; ++u) { d[u][g] = __builtin_amdgcn_exp2f(d[u][g] - mn); l[g] += d[u][g]; }
+      m[g] = mn;
+    }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      float vf[EPL];
+      raw_to_f32<T, EPL, NW32>(vr[u], vf);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[g][e] = fmaf(d[u][g], vf[e], o[g][e]);
+    }
+  };
+
+  for (int base = s0; base < send; base += 4 * NWV * U) {     // uniform trip count
+    if (base != s0) issue_kv(base);
+    block(kr, vr, ok, std::integral_constant<int, U>{});
+  }
+  if (owner && wave == 0) {                      // the new key, from registers (wave-uniform branch)
+    uint32_t k1[1][NW32], v1[1][NW32];
+#pragma unroll
+    for (int i = 0; i < NW32; ++i) { k1[0][i] = knr[i]; v1[0][i] = vnr[i]; }
+    const bool ok1[1] = {gq == 0};
+    block(k1, v1, ok1, std::integral_constant<int, 1>{});
+  }
+
+  // ---- merge the four lane groups of the wave (lanes li, li+16, li+32, li+48), then the waves
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float mo = __shfl_xor(m[g], off, 64);
+      const float lo = __shfl_xor(l[g], off, 64);
+      const float mn = fmaxf(m[g], mo);
+      const float ca = __builtin_amdgcn_exp2f(m[g] - mn), cb = __builtin_amdgcn_exp2f(mo - mn);
+      l[g] = l[g] * ca + lo * cb;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const float oo = __shfl_xor(o[g][e], off, 64);
+        o[g][e] = o[g][e] * ca + oo * cb;
+      }
+      m[g] = mn;
+    }
+    if (gq == 0) {
+      if (li == 0) { st_m[wave][g] = m[g]; st_l[wave][g] = l[g]; }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) st_o[wave][g][li * EPL + e] = o[g][e];
+    }
+  }
+  __syncthreads();
+  T* out = (T*)c.out + (size_t)b * nq;
+  for (int idx = tid; idx < G * D; idx += 512) {
+    const int g = idx / D, d = idx % D;
+    float mn = -1e30f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) mn = fmaxf(mn, st_m[w][g]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const float cw = __builtin_amdgcn_exp2f(st_m[w][g] - mn);
+      L = fmaf(st_l[w][g], cw, L);
+      O = fmaf(st_o[w][g][d], cw, O);
+    }
+    const int h = kh * G + g;
+    if (c.nsplit == 1) {
+      out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
+    } else {
+      float* pp = c.partial + (((size_t)b * s.Hq + h) * c.nsplit + split) * (D + 2);
+      pp[2 + d] = O;
+      if (d == 0) { pp[0] = mn; pp[1] = L; }
+    }
+  }
+  if (c.nsplit == 1) return;
+
+  // ---- publish, take a ticket; the last split of this (b, kv-head) combines
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&c.counters[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == c.nsplit - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&c.counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    is_last_sh = last;
+  }
+  __syncthreads();
+  if (!is_last_sh) return;
+  for (int idx = tid; idx < G * D; idx += 512) {
+    const int g = idx / D, d = idx % D, h = kh * G + g;
+    const float* pp = c.partial + ((size_t)b * s.Hq + h) * c.nsplit * (D + 2);
+    float mn = -1e30f;
+    for (int i = 0; i < c.nsplit; ++i) mn = fmaxf(mn, pp[i * (D + 2)]);
+    float L = 0.f, O = 0.f;
+    for (int i = 0; i < c.nsplit; ++i) {
+      const float cw = __builtin_amdgcn_exp2f(pp[i * (D + 2)] - mn);
+      L = fmaf(pp[i * (D + 2) + 1], cw, L);
+      O = fmaf(pp[i * (D + 2) + 2 + d], cw, O);
+    }
+    out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
+  }
+}
+
+template <typename T, int D>
+int launch_g(const AttnDecodeCall& c, hipStream_t st) {
+  const AttnShape& s = c.s;
+  const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
+  switch (s.Hq / s.Hkv) {
+    case 1: hipLaunchKernelGGL((attn_decode_kernel<T, D, 1>), grid, block, 0, st, c); break;
+    case 2: hipLaunchKernelGGL((attn_decode_kernel<T, D, 2>), grid, block, 0, st, c); break;
+    case 4: hipLaunchKernelGGL((attn_decode_kernel<T, D, 4>), grid, block, 0, st, c); break;
+    case 5: hipLaunchKernelGGL((attn_decode_kernel<T, D, 5>), grid, block, 0, st, c); break;
+    case 8: hipLaunchKernelGGL((attn_decode_kernel<T, D, 8>), grid, block, 0, st, c); break;
+    default: return fail(MI_ERR_UNSUPPORTED, "attention: Hq/Hkv must be 1, 2, 4, 5 or 8");
+  }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+template <typename T>
+int launch_d(const AttnDecodeCall& c, hipStream_t st) {
+  switch (c.s.D) {
+    case 16: if constexpr (sizeof(T) == 4) return launch_g<T, 16>(c, st); break;
+    case 32: return launch_g<T, 32>(c, st);
+    case 64: return launch_g<T, 64>(c, st);
+    case 128: return launch_g<T, 128>(c, st);
+  }
+  return fail(MI_ERR_UNSUPPORTED, "attention_decode: head_dim not supported by the fused kernel");
+}
+
+}  // namespace
+
+bool attention_decode_supported(const AttnShape& s) {
+  if (s.L != 1 || s.act != s.kv) return false;
+  const int G = s.Hkv > 0 ? s.Hq / s.Hkv : 0;
+  if (!(G == 1 || G == 2 || G == 4 || G == 5 || G == 8)) return false;
+  if (s.act == MI_F32) return s.D == 16 || s.D == 32 || s.D == 64 || s.D == 128;
+  return s.D == 32 || s.D == 64 || s.D == 128;
+}
+
+int launch_attention_decode(const AttnDecodeCall& c, hipStream_t st) {
+  const AttnShape& s = c.s;
+  if (!attention_decode_supported(s)) return fail(MI_ERR_UNSUPPORTED, "attention_decode: shape / dtype not supported");
+  if (c.nsplit < 1 || (c.nsplit > 1 && (c.partial == nullptr || c.counters == nullptr)))
+    return fail(MI_ERR_INVALID, "attention_decode: bad split configuration");
+  if (s.act == MI_F32) return launch_d<float>(c, st);
+  if (s.act == MI_BF16) return launch_d<bf16>(c, st);
+  return launch_d<f16>(c, st);
+}
+
+}  // namespace mi

@@ -56,8 +56,12 @@ template <typename T>
 __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
 // value -> storage type T with the run-time logical rounding applied first
+// (a 16-bit storage type IS the logical dtype: the run-time mode only matters for float storage)
 template <typename T>
-__device__ __forceinline__ T store_act(float v, int rnd) { return (T)round_rt(v, rnd); }
+__device__ __forceinline__ T store_act(float v, int rnd) {
+  if constexpr (sizeof(T) == 4) return (T)round_rt(v, rnd);
+  else return (T)v;
+}
 
 // scale * q + bias with two roundings (the oracle's `q * scale + bias`); hipcc would otherwise
 // contract it into one FMA (-ffp-contract=fast is the HIP default, and __fmul_rn is a plain `*`).

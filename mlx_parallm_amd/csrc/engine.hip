@@ -93,6 +93,7 @@ struct mi_engine {
   std::string prof_name;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   int opt_force_v1 = 0;
+  int opt_fused_attn = 1;
 };
 
 struct mi_kv {
@@ -103,6 +104,7 @@ struct mi_kv {
   int32_t* d_off = nullptr;
   std::vector<int32_t> h_off;
   float* partial = nullptr; int partial_splits = 0;
+  int* counters = nullptr;       // [B*Hkv] split-arrival tickets of the fused decode attention
 };
 
 namespace {
@@ -340,14 +342,22 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap};
     void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
-    { Prof pr(e, "rope_append");
-      RopeAppendCall rc{s, e->qkv, e->q, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps,
-                        e->cos_tab, e->sin_tab, d.max_positions};
-      MI_TRY(launch_rope_append(rc, st)); }
-    { Prof pr(e, "attn");
-      AttnShape sa = s; sa.rnd = RND_NONE;  // SDPA output dtype = promote(q, kv): float32 in quirk mode
-      AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial};
-      MI_TRY(launch_attention(ac, st)); }
+    if (L == 1 && e->opt_fused_attn && attention_decode_supported(s)) {
+      // decode: norm + RoPE + append + attention + split combine in one launch
+      Prof pr(e, "attn");
+      AttnDecodeCall ac{s, e->qkv, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab,
+                        e->attn, 1.0f / sqrtf((float)D), RND_NONE, nsplit, kv->partial, kv->counters};
+      MI_TRY(launch_attention_decode(ac, st));
+    } else {
+      { Prof pr(e, "rope_append");
+        RopeAppendCall rc{s, e->qkv, e->q, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps,
+                          e->cos_tab, e->sin_tab, d.max_positions};
+        MI_TRY(launch_rope_append(rc, st)); }
+      { Prof pr(e, "attn");
+        AttnShape sa = s; sa.rnd = RND_NONE;  // SDPA output dtype = promote(q, kv): float32 in quirk mode
+        AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial};
+        MI_TRY(launch_attention(ac, st)); }
+    }
     {  // o_proj + residual (llama.py:143,188)
       GemvCall c; c.x = e->attn; c.ldx = Hq * D; c.act = act; c.rnd = RND_NONE; c.epi = EPI_RESID;
       c.resid = e->h; c.ldo = H;
@@ -610,11 +620,14 @@ int mi_kv_create(mi_engine* e, int batch, int capacity_tokens, int kv_dtype, mi_
   else if (kv_dtype == MI_F32) { kv->dtype = MI_F32; kv->quirk = true; }
   else { delete kv; return fail(MI_ERR_UNSUPPORTED, "kv dtype must be the model dtype or float32"); }
   const size_t bytes = (size_t)e->d.num_layers * batch * e->d.num_kv_heads * capacity_tokens * e->d.head_dim * dtype_size(kv->dtype);
+  const size_t nctr = (size_t)batch * e->d.num_kv_heads;
   if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess ||
-      hipMalloc(&kv->d_off, batch * sizeof(int32_t)) != hipSuccess) {
-    hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); delete kv;
+      hipMalloc(&kv->d_off, batch * sizeof(int32_t)) != hipSuccess ||
+      hipMalloc(&kv->counters, nctr * sizeof(int)) != hipSuccess) {
+    hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->counters); delete kv;
     return fail(MI_ERR_RUNTIME, "out of device memory allocating the KV cache");
   }
+  MI_HIP(hipMemsetAsync(kv->counters, 0, nctr * sizeof(int), e->stream));
   // zero-filled like the reference's mx.zeros (base.py:71-72,111-112)
   MI_HIP(hipMemsetAsync(kv->k, 0, bytes, e->stream));
   MI_HIP(hipMemsetAsync(kv->v, 0, bytes, e->stream));
@@ -629,7 +642,7 @@ void mi_kv_destroy(mi_kv* kv) {
   if (!kv) return;
   hipSetDevice(kv->e->device);
   hipStreamSynchronize(kv->e->stream);
-  hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->partial);
+  hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->partial); hipFree(kv->counters);
   delete kv;
 }
 
@@ -771,6 +784,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (!e || !key) return fail(MI_ERR_INVALID, "null argument");
   const std::string k(key);
   if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
+  if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
   return fail(MI_ERR_NOTFOUND, "unknown option: " + k);
 }
 

@@ -94,6 +94,28 @@ struct AttnCall {
 };
 int launch_attention(const AttnCall& c, hipStream_t st);
 
+// fused decode step (L == 1): q/k norm + RoPE + KV append + split-KV attention + combine
+struct AttnDecodeCall {
+  AttnShape s;             // s.rnd = logical rounding of q / k after norm and RoPE
+  const void* qkv;         // [B][(Hq+2Hkv)*D] raw projections
+  void* kcache;
+  void* vcache;
+  const int32_t* offsets;  // device [B]: tokens already in the cache
+  const void* q_norm_w;
+  const void* k_norm_w;
+  float eps;
+  const float* cos_tab;
+  const float* sin_tab;
+  void* out;               // [B][Hq*D]
+  float scale;
+  int rnd_out;             // logical rounding of the attention output
+  int nsplit;
+  float* partial;          // [B*Hq][nsplit][D+2]
+  int* counters;           // [B*Hkv] zero-initialised arrival tickets
+};
+int launch_attention_decode(const AttnDecodeCall& c, hipStream_t st);
+bool attention_decode_supported(const AttnShape& s);
+
 struct SampleCall {
   float* logits;         // [B][V] float32 (modified in place by logit_bias)
   int B, V;

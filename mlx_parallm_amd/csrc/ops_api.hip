@@ -115,6 +115,32 @@ int mi_op_attention(const mi_op_attn_shape* s, const void* q, const void* kcache
   return finish();
 }
 
+int mi_op_attention_decode(const mi_op_attn_shape* s, const void* qkv, void* kcache, void* vcache,
+                           const int32_t* offsets, const void* q_norm_w, const void* k_norm_w, float eps,
+                           const float* cos_tab, const float* sin_tab, void* out, float scale, int rnd_out,
+                           int nsplit, float* partial, int32_t* counters, int iters, float* avg_ms) {
+  if (!s) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  AttnDecodeCall ac{to_shape(s), qkv, kcache, vcache, offsets, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
+                    out, scale, rnd_out, nsplit, partial, (int*)counters};
+  if (iters <= 1) {
+    MI_TRY(launch_attention_decode(ac, nullptr));
+    return finish();
+  }
+  hipEvent_t e0, e1;
+  MI_HIP(hipEventCreate(&e0)); MI_HIP(hipEventCreate(&e1));
+  MI_TRY(launch_attention_decode(ac, nullptr));
+  MI_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) MI_TRY(launch_attention_decode(ac, nullptr));
+  MI_HIP(hipEventRecord(e1, nullptr));
+  MI_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MI_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_ms) *avg_ms = ms / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return finish();
+}
+
 int mi_op_sample(float* logits, int B, int V, float temperature, float top_p, const float* uniforms,
                  int top_logprobs, int32_t* tokens_out, float* logprob_out, float* prob_row0_out,
                  int32_t* topk_ids, float* topk_logprobs, float* row_stats) {

@@ -149,6 +149,15 @@ class _KVPool:
 _kv_pool = _KVPool()
 
 
+def _take(gen, n: int):
+    """``enumerate(first n items of gen)``.  The reference writes ``zip(generate_step(...),
+    range(max_tokens))``, which pulls one item more than it uses before ``range`` runs out --
+    i.e. computes and waits for a step whose tokens are thrown away; this does not."""
+    import itertools
+
+    return enumerate(itertools.islice(gen, n))
+
+
 # --------- generation (utils.py:315-427) ---------
 def generate_step(
     prompts,
@@ -216,7 +225,7 @@ def stream_generate(model, tokenizer, prompt: str, max_tokens: int = 100, **kwar
     prompt_tokens = np.asarray(tokenizer.encode(prompt), dtype=np.int32)[None, :]
     detokenizer = tokenizer.detokenizer
     detokenizer.reset()
-    for (token, _prob), _n in zip(generate_step(prompt_tokens, model, **kwargs), range(max_tokens)):
+    for _n, (token, _prob) in _take(generate_step(prompt_tokens, model, **kwargs), max_tokens):
         token_item = int(token[0, 0])
         if token_item == tokenizer.eos_token_id:
             break
@@ -247,7 +256,7 @@ def batch_generate(model, tokenizer, prompts: List[str], max_tokens: int = 100, 
     tic = time.perf_counter()
     output_toks = []
     prompt_time = 0.0
-    for (tokens, _), n in zip(generate_step(prompts_toks, model, **kwargs), range(max_tokens)):
+    for n, (tokens, _) in _take(generate_step(prompts_toks, model, **kwargs), max_tokens):
         if n == 0:
             prompt_time = time.perf_counter() - tic
             tic = time.perf_counter()
@@ -282,7 +291,7 @@ def generate(model, tokenizer, prompt: str, max_tokens: int = 100, verbose: bool
     detokenizer.reset()
     prompt_time = 0.0
     n = -1
-    for (token, prob), n in zip(generate_step(prompt_tokens, model, **kwargs), range(max_tokens)):
+    for n, (token, prob) in _take(generate_step(prompt_tokens, model, **kwargs), max_tokens):
         if n == 0:
             prompt_time = time.perf_counter() - tic
             tic = time.perf_counter()
@@ -425,7 +434,7 @@ def batch_stream_generate_text(model, tokenizer, prompts_tokens, max_tokens: int
     counts = [0] * batch_size
     eos_token_id = tokenizer.eos_token_id
     step_kwargs = {k: v for k, v in kwargs.items() if k != "repetition_penalty"}    # utils.py:1028
-    for (ids, _), _ in zip(generate_step(prompts_tokens, model, **step_kwargs), range(max_tokens)):
+    for _, (ids, _p) in _take(generate_step(prompts_tokens, model, **step_kwargs), max_tokens):
         deltas: List[Tuple[Optional[str], Optional[str]]] = [(None, None)] * batch_size
         any_active = False
         for i in range(batch_size):

@@ -1,0 +1,103 @@
+"""A stand-in for the device engine, backed by the oracle, so that the HOST logic of
+mlx_parallm_amd.utils (generation loop, pipelining order, padding, EOS bookkeeping, KV pooling)
+can be tested on a GPU-less machine.  Test infrastructure: it lives under tests/ and is never
+importable from the product package."""
+from __future__ import annotations
+
+import numpy as np
+
+from mlx_parallm_amd.models.base import BatchedKVCache, PagedKVCache, group_of, make_cache_list
+from oracle import ref_generate, ref_sample
+
+
+class FakeKV:
+    def __init__(self, engine, ref_caches, batch_size, kv_dtype):
+        self.engine, self.caches, self.batch_size, self.kv_dtype = engine, ref_caches, batch_size, kv_dtype
+        self.step = 256
+        self.closed = False
+
+    @property
+    def offsets(self):
+        return self.caches[0].offsets
+
+    def reset(self, batch_size=None):
+        for c in self.caches:
+            c.reset(batch_size)
+
+    def ensure(self, n):
+        pass
+
+    def close(self):
+        self.closed = True
+
+
+class FakeEngine:
+    """step_enqueue computes eagerly (there is no device) but hands results out only through
+    step_wait, and records the call order so tests can check the one-step-ahead pipelining."""
+
+    def __init__(self, ref_model):
+        self.ref = ref_model
+        self.trace = []
+        self._results = {}
+        self._next = 0
+        self._last_tokens = None
+
+    def forward(self, tokens, kv, all_positions=False, want_logits=True):
+        lg = self.ref(np.asarray(tokens), cache=kv.caches)
+        self.trace.append(("forward", np.asarray(tokens).shape))
+        if not want_logits:
+            return None
+        return lg if all_positions else lg[:, -1]
+
+    def step_enqueue(self, kv, tokens=None, sample=None, L_tokens=1):
+        if tokens is None:
+            tokens = self._last_tokens
+            self.trace.append(("enqueue", "device-tokens"))
+        else:
+            tokens = np.asarray(tokens)
+            self.trace.append(("enqueue", tokens.shape))
+        logits = self.ref(tokens, cache=kv.caches)[:, -1]
+        c = sample.c
+        bias = None
+        if c.n_logit_bias:
+            bias = {int(c.logit_bias_ids[i]): float(c.logit_bias_values[i]) for i in range(c.n_logit_bias)}
+        u = getattr(sample, "_u", None) if c.uniforms else None
+        if c.temperature != 0 and u is None:
+            u = np.random.default_rng(int(c.seed) + self._next).random(tokens.shape[0])
+        s = ref_sample.sample(logits, temp=float(c.temperature), top_p=float(c.top_p), logit_bias=bias, uniforms=u)
+        self._last_tokens = s["tokens"]
+        t = self._next
+        self._next += 1
+        self._results[t] = {"tokens": s["tokens"][:, 0].astype(np.int32), "logprobs": s["logprobs"],
+                            "probs_row0": s["probs"][:, 0]}
+        return t
+
+    def step_wait(self, ticket, batch_size, top_logprobs=0):
+        self.trace.append(("wait", ticket))
+        return self._results.pop(ticket)
+
+
+class _Layer:
+    pass
+
+
+class FakeModel:
+    def __init__(self, model_dir, max_pos=1024):
+        self.ref = ref_generate.load(model_dir, max_pos=max_pos)
+        self.engine = FakeEngine(self.ref)
+        cfg = self.ref.cfg
+        self.layers = [_Layer() for _ in range(cfg.num_hidden_layers)]
+        self.head_dim = cfg.head_dim
+        self.n_kv_heads = cfg.num_key_value_heads
+
+    def bind_cache(self, cache, batch, new_tokens):
+        g = group_of(cache)
+        if g.batch_size != batch:
+            raise ValueError("PagedKVCache batch size mismatch")
+        if g.handle is None or g.handle.engine is not self.engine or g.handle.batch_size != batch:
+            g.handle = FakeKV(self.engine, self.ref.make_cache(batch, paged=(g.kv_dtype == "float32")), batch, g.kv_dtype)
+        return g.handle
+
+    def make_cache(self, batch_size, paged=True, step=None):
+        kv_heads = [self.n_kv_heads] * len(self.layers)
+        return make_cache_list(PagedKVCache if paged else BatchedKVCache, self.head_dim, kv_heads, batch_size, step)

@@ -134,6 +134,35 @@ def test_greedy_model_dtype_kv_16bit_models(tiny_dirs, name):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_f32", "llama_bf16_gqa", "qwen3_bf16"])
+def test_fused_and_unfused_decode_attention_agree(tiny_dirs, name):
+    """The one-launch decode attention (norm + RoPE + append + split-KV + in-kernel combine) against
+    the three-launch form, long enough context that the KV range is split across workgroups."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    B, L0 = 2, 200
+    toks = _left_pad_prompts(cfg, B, L0, ragged=False)
+    outs = []
+    for fused in (1, 0):
+        model.engine.set_option("fused_decode_attention", fused)
+        kv = model.engine.new_kv(B, capacity=256, kv_dtype="model")
+        model.engine.forward(toks, kv, want_logits=False)
+        y = toks[:, -1:]
+        steps = []
+        for _ in range(4):
+            lg = model.engine.forward(y, kv)
+            steps.append(lg)
+            y = np.argmax(lg, axis=-1)[:, None].astype(np.int32)
+        outs.append(np.stack(steps))
+        kv.close()
+    tol = 2e-4 if name == "llama_f32" else 0.08
+    assert np.abs(outs[0] - outs[1]).max() <= tol, np.abs(outs[0] - outs[1]).max()
+    cache = ref.make_cache(B, paged=False)
+    ref(toks, cache=cache)
+    want = ref(toks[:, -1:], cache=cache)[:, -1]
+    assert np.abs(outs[0][0] - want).max() <= tol
+    model.engine.close()
+
+
 def test_generate_step_pipelined_matches_oracle_generate_step(tiny_dirs):
     """utils.generate_step (one-step-ahead pipelining, device-resident token feedback) == the
     oracle's generate_step on the reference's default cache (paged)."""

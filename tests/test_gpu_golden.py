@@ -1,0 +1,52 @@
+"""-m gpu: the HIP path against the committed golden vectors (tests/golden/*.npz), through
+utils.load_model -> engine -> C ABI.  Teacher-forced with the golden tokens: at every step the
+device's token must be the golden one unless the golden top-2 margin is inside the documented error
+bound of the configuration (counted, must stay rare); chosen-token logprobs within 1e-3 on the
+float32-KV (reference-default) cases."""
+import json
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from mlx_parallm_amd import utils  # noqa: E402
+from mlx_parallm_amd.engine import SampleArgs  # noqa: E402
+from mlx_parallm_amd.tiny_model import build_tiny_model  # noqa: E402
+
+GOLDEN = sorted((Path(__file__).resolve().parent / "golden").glob("*.npz"))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[p.stem for p in GOLDEN])
+def test_device_matches_golden(path):
+    g = np.load(path)
+    spec = json.loads(str(g["spec"]))
+    dtype16 = spec["model"].get("dtype", "float32") != "float32"
+    # float32 activations everywhere (float32 model or PagedKVCache mode): fp32 accumulation noise only
+    exact = (not dtype16) or spec["paged"]
+    eps = 1e-3 if exact else 0.13
+    with tempfile.TemporaryDirectory() as d:
+        build_tiny_model(d, **spec["model"])
+        model = utils.load_model(d, max_positions=256)
+        B = g["prompts"].shape[0]
+        kv = model.engine.new_kv(B, capacity=64, kv_dtype="float32" if spec["paged"] else "model")
+        y = g["prompts"]
+        near = 0
+        for s in range(spec["steps"]):
+            sp = SampleArgs(temp=spec["temp"], top_p=spec["top_p"], uniforms=g["uniforms"][s] if spec["temp"] else None,
+                            top_logprobs=2)
+            res = model.engine.decode_sample(kv, y.astype(np.int32), sp)
+            want = g["tokens"][s]
+            for b in range(B):
+                if res["tokens"][b] != want[b]:
+                    if spec["temp"] == 0.0:
+                        assert g["margins"][s, b] <= eps and res["tokens"][b] in g["top_ids"][s, b, :3], (path.stem, s, b)
+                    near += 1
+                elif exact:
+                    assert abs(res["logprobs"][b] - g["logprobs"][s, b]) <= 1e-3
+            y = want[:, None]
+        total = spec["steps"] * B
+        assert near <= (0 if exact and spec["temp"] == 0.0 and g["margins"].min() > eps else max(1, total // 10)), (near, total)
+        model.engine.close()
