@@ -55,6 +55,8 @@ typedef struct mi_op_linear {
   const void* w;         /* [N][K] dense, or MLX-packed [N][K*bits/32] */
   const void* scales;    /* [N][K/group] */
   const void* biases;
+  int32_t layout;        /* 0 = row-major (checkpoint order), 1 = tile-major (mi_op_repack_tiled; then w is
+                            the tiled buffer and scales/biases are unused) */
 } mi_op_linear;
 
 typedef struct mi_op_gemv_args {
@@ -81,6 +83,10 @@ int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a);
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a);
 /* launches the same call `iters` times back to back and returns the mean launch time (HIP events) */
 int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
+/* tile-major weight layout of the streaming kernels (what mi_engine_finalize applies to eligible
+ * matrices): returns the size of the tiled buffer (0 if the matrix is not eligible) / fills `dst`. */
+uint64_t mi_op_tiled_bytes(const mi_op_linear* row_major);
+int mi_op_repack_tiled(const mi_op_linear* row_major, void* dst);
 int mi_op_embed(const mi_op_linear* w, const int32_t* tokens, int rows, int act, int rnd, void* out);
 int mi_op_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int head_dim, float base, float scale);
 int mi_op_rope_append(const mi_op_attn_shape* s, const void* qkv, void* q_out, void* kcache, void* vcache,

@@ -46,7 +46,7 @@ class SampleParams(C.Structure):
 
 class OpLinear(C.Structure):
     _fields_ = [("wk", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("group", C.c_int32),
-                ("w", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p)]
+                ("w", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p), ("layout", C.c_int32)]
 
 
 class OpGemvArgs(C.Structure):
@@ -92,6 +92,8 @@ SIGNATURES = {
     "mi_op_gemv": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs)]),
     "mi_op_gemv_uses_mfma": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs)]),
     "mi_op_gemv_bench": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_float)]),
+    "mi_op_tiled_bytes": (C.c_uint64, [C.POINTER(OpLinear)]),
+    "mi_op_repack_tiled": (C.c_int, [C.POINTER(OpLinear), _P]),
     "mi_op_embed": (C.c_int, [C.POINTER(OpLinear), _P, C.c_int, C.c_int, C.c_int, _P]),
     "mi_op_rope_tables": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float]),
     "mi_op_rope_append": (C.c_int, [C.POINTER(OpAttnShape), _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int]),

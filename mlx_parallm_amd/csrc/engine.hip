@@ -94,6 +94,7 @@ struct mi_engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   int opt_force_v1 = 0;
   int opt_fused_attn = 1;
+  int opt_tile_weights = 1;
 };
 
 struct mi_kv {
@@ -190,6 +191,17 @@ int finalize_linear(mi_engine* e, FusedLinear& f, int K, const std::string& name
   f.W.wk = kind_of(f, e->d.quant_bits);
   f.W.w = f.w; f.W.scales = f.scales; f.W.biases = f.biases;
   f.W.N = total; f.W.K = K; f.W.group = e->d.quant_group_size > 0 ? e->d.quant_group_size : 64;
+  // "repack weights": tile-major layout for the matrices the streaming kernels read (repack.hip)
+  if (e->opt_tile_weights && tiled_supported(f.W.wk, f.W.N, f.W.K, f.W.group)) {
+    void* dst = nullptr;
+    if (hipMalloc(&dst, tiled_bytes(f.W.wk, f.W.N, f.W.K)) != hipSuccess)
+      return fail(MI_ERR_RUNTIME, name + ": out of device memory repacking weights");
+    MI_TRY(launch_repack_tiled(f.W, dst, e->stream));
+    MI_HIP(hipStreamSynchronize(e->stream));
+    hipFree(f.w); hipFree(f.scales); hipFree(f.biases);
+    f.w = dst; f.scales = nullptr; f.biases = nullptr;
+    f.W.w = dst; f.W.scales = nullptr; f.W.biases = nullptr; f.W.layout = 1;
+  }
   return MI_OK;
 }
 
@@ -785,6 +797,10 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   const std::string k(key);
   if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
   if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
+  if (k == "tile_weights") {
+    if (e->finalized) return fail(MI_ERR_INVALID, "tile_weights must be set before mi_engine_finalize");
+    e->opt_tile_weights = value != 0; return MI_OK;
+  }
   return fail(MI_ERR_NOTFOUND, "unknown option: " + k);
 }
 

@@ -37,7 +37,7 @@ struct MfmaParams {
   const void* w; const void* scales; const void* biases;
   int N, K;
   int epi; void* out; int ldo; void* resid; int pair_offset;
-  int ntiles;   // 16-row tiles (SWIGLU: gate tiles)
+  int layout;       // always 1 here: tile-major (16 rows x 32 k blocks of 1 KiB, repack.hip)
   int kc;       // K elements staged in LDS per chunk
   const float* lora_t; int lora_t_ld;
   const float* lora_b0; const float* lora_b1;
@@ -129,33 +129,46 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const AT* x = (const AT*)p.x;
-  const int nbatch = (p.ntiles + TB - 1) / TB;
+  // Work items of this workgroup: 16-row tiles dealt round-robin (tile = w + i*G), so that
+  // neighbouring workgroups stream neighbouring memory.  (Cutting the left-over tiles into 8-row
+  // halves to balance the CUs was measured and lost: +10 % on q|k|v, the extra item costs more
+  // than the imbalance.)
+  const int G = gridDim.x, w = blockIdx.x;
+  const int ntiles_all = p.N / 16;
+  const int ntiles = (ntiles_all - w + G - 1) / G;   // items of this workgroup
+  const int nbatch = (ntiles + TB - 1) / TB;
   const int nchunks = (p.K + p.kc - 1) / p.kc;
-  int tb = blockIdx.x;
-  if (tb >= nbatch) return;
+  int tb = 0;
+  if (ntiles <= 0) return;
+  auto item_row0 = [&](int i) -> int { return min(w + i * G, ntiles_all - 1) * 16; };
 
   u32x4 wr[NA][TB][UK];
   uint32_t sr[NA][TB][UK], br[NA][TB][UK];
   u32x4 xv[MB][J];
 
-  // ---- issue slot u of the weight loads of batch (tbi, [k0, k0+KS) clipped to kend)
+  // ---- issue slot u of the weight loads of batch (tbi, [k0, k0+KS) clipped to kend).
+  // STRAIGHT-LINE on purpose: a load under a branch makes hipcc wait vmcnt(0) at the join, which
+  // drains the whole prefetch queue at every step.  Slots past kend / items past the end load a
+  // valid (already cached) address instead and are zeroed or ignored by the consumer.
   auto issue_u = [&](int u, int tbi, int k0, int kend) {
-    const int k = k0 + (u * NW + wave) * BK;
-    if (k < kend) {
+    const int kq = k0 + (u * NW + wave) * BK;
+    const int k = kq < kend ? kq : 0;
 #pragma unroll
-      for (int t = 0; t < TB; ++t) {
-        const int tile = min(tbi * TB + t, p.ntiles - 1);
-        const int row = tile * 16 + c16;
+    for (int t = 0; t < TB; ++t) {
+      const int row = item_row0(tbi * TB + t) + c16;
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-          const size_t rowa = (size_t)(row + a * p.pair_offset);
-          if constexpr (!Q4) {
-            wr[a][t][u] = __builtin_nontemporal_load((const u32x4*)((const AT*)p.w + rowa * p.K + k + g * 8));
-          } else {
-            wr[a][t][u] = __builtin_nontemporal_load((const u32x4*)((const uint32_t*)p.w + rowa * (p.K / 8) + k / 8 + g * 4));
-            sr[a][t][u] = *(const uint32_t*)((const S*)p.scales + rowa * (p.K / 64) + k / 64);
-            br[a][t][u] = *(const uint32_t*)((const S*)p.biases + rowa * (p.K / 64) + k / 64);
-          }
+      for (int a = 0; a < NA; ++a) {
+        const size_t rowa = (size_t)(row + a * p.pair_offset);
+        // tile-major weights (repack.hip): the 16-row x BK-k block of this load is ONE contiguous KiB
+        // (+128 B of scales/biases for int4), lane l at 16 l; consecutive k blocks are consecutive
+        if constexpr (!Q4) {
+          const char* blk = (const char*)p.w + ((rowa >> 4) * (size_t)(p.K / 32) + (size_t)(k >> 5)) * 1024;
+          wr[a][t][u] = __builtin_nontemporal_load((const u32x4*)(blk + (g * 16 + (int)(rowa & 15)) * 16));
+        } else {
+          const char* blk = (const char*)p.w + ((rowa >> 4) * (size_t)(p.K / 128) + (size_t)(k >> 7)) * 1152;
+          wr[a][t][u] = __builtin_nontemporal_load((const u32x4*)(blk + (g * 16 + (int)(rowa & 15)) * 16));
+          sr[a][t][u] = *(const uint32_t*)(blk + 1024 + (int)(rowa & 15) * 4);
+          br[a][t][u] = *(const uint32_t*)(blk + 1088 + (int)(rowa & 15) * 4);
         }
       }
     }
@@ -232,58 +245,58 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
 
   // ---- MFMAs of slot u of batch [k0, k0+KS) clipped to kend; fragments are addressed relative to cbase
   auto mfma_u = [&](int u, int k0, int kend, int cbase) {
-    {
-      const int k = k0 + (u * NW + wave) * BK;
-      if (k < kend) {
-        const int kb = (k - cbase) / BK;
-        if constexpr (!Q4) {
-          u32x4 af = {0u, 0u, 0u, 0u};
-          if (MB == 16 || c16 < MB) af = frag[(kb * 4 + g) * MB + c16];
+    const int kq = k0 + (u * NW + wave) * BK;
+    const bool valid = kq < kend;                     // wave-uniform; an invalid slot multiplies zeros
+    const int kb = valid ? (kq - cbase) / BK : 0;
+    const bool lane_on = valid && (MB == 16 || c16 < MB);
+    const int cm = c16 & (MB - 1);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    if constexpr (!Q4) {
+      u32x4 af = frag[(kb * 4 + g) * MB + cm];
+      af = lane_on ? af : zero4;
 #pragma unroll
-          for (int t = 0; t < TB; ++t)
+      for (int t = 0; t < TB; ++t)
 #pragma unroll
-            for (int a = 0; a < NA; ++a) acc[a][t] = mfma16<AT>(af, wr[a][t][u], acc[a][t]);
-        } else {
-          u32x4 af[2][2];
-          f32x4 sxv[2];
+        for (int a = 0; a < NA; ++a) acc[a][t] = mfma16<AT>(af, wr[a][t][u], acc[a][t]);
+    } else {
+      u32x4 af[2][2];
+      f32x4 sxv[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          af[s][t2] = frag[((((kb * 2 + s) * 2 + t2) * 4 + g) * MB + cm)];
+          af[s][t2] = lane_on ? af[s][t2] : zero4;
+        }
+        sxv[s] = *(const f32x4*)&sx[(kb * 2 + s) * MB + ((g * 4) & (MB - 1))];
+        if (!(valid && (MB == 16 || g * 4 < MB))) sxv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int t = 0; t < TB; ++t)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          // lanes g<2 hold quant group A (dwords 0-7 of the 128 block), g>=2 group B.  Swap the
+          // upper half's {x,y} with the lower half's {z,w}: afterwards {x,y} = group A and
+          // {z,w} = group B in EVERY lane (v_permlane32_swap).
+          u32x4 v = wr[a][t][u];
+          auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+          const uint32_t dw[4] = {r0[0], r1[0], r0[1], r1[1]};
+          const S* sp = (const S*)&sr[a][t][u];
+          const S* bp = (const S*)&br[a][t][u];
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-              af[s][t2] = u32x4{0u, 0u, 0u, 0u};
-              if (MB == 16 || c16 < MB) af[s][t2] = frag[((((kb * 2 + s) * 2 + t2) * 4 + g) * MB + c16)];
-            }
-            sxv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (MB == 16 || g * 4 < MB) sxv[s] = *(const f32x4*)&sx[(kb * 2 + s) * MB + g * 4];
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mfma16<AT>(af[s][0], unpack_q4<AT>(dw[s * 2 + 0]), d);
+            d = mfma16<AT>(af[s][1], unpack_q4<AT>(dw[s * 2 + 1]), d);
+            // y += scale * sum((OFFS+q) x) + (bias - OFFS*scale) * sum(x)   per output row m
+            const float sc = (float)sp[s], bb = (float)bp[s] - Magic<AT>::offs * sc;
+            acc[a][t].x = fmaf(sc, d.x, fmaf(bb, sxv[s].x, acc[a][t].x));
+            acc[a][t].y = fmaf(sc, d.y, fmaf(bb, sxv[s].y, acc[a][t].y));
+            acc[a][t].z = fmaf(sc, d.z, fmaf(bb, sxv[s].z, acc[a][t].z));
+            acc[a][t].w = fmaf(sc, d.w, fmaf(bb, sxv[s].w, acc[a][t].w));
           }
-#pragma unroll
-          for (int t = 0; t < TB; ++t)
-#pragma unroll
-            for (int a = 0; a < NA; ++a) {
-              // lanes g<2 hold quant group A (dwords 0-7 of the 128 block), g>=2 group B.  Swap the
-              // upper half's {x,y} with the lower half's {z,w}: afterwards {x,y} = group A and
-              // {z,w} = group B in EVERY lane (v_permlane32_swap).
-              u32x4 v = wr[a][t][u];
-              auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
-              auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
-              const uint32_t dw[4] = {r0[0], r1[0], r0[1], r1[1]};
-              const S* sp = (const S*)&sr[a][t][u];
-              const S* bp = (const S*)&br[a][t][u];
-#pragma unroll
-              for (int s = 0; s < 2; ++s) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
-                d = mfma16<AT>(af[s][0], unpack_q4<AT>(dw[s * 2 + 0]), d);
-                d = mfma16<AT>(af[s][1], unpack_q4<AT>(dw[s * 2 + 1]), d);
-                // y += scale * sum((OFFS+q) x) + (bias - OFFS*scale) * sum(x)   per output row m
-                const float sc = (float)sp[s], bb = (float)bp[s] - Magic<AT>::offs * sc;
-                acc[a][t].x = fmaf(sc, d.x, fmaf(bb, sxv[s].x, acc[a][t].x));
-                acc[a][t].y = fmaf(sc, d.y, fmaf(bb, sxv[s].y, acc[a][t].y));
-                acc[a][t].z = fmaf(sc, d.z, fmaf(bb, sxv[s].z, acc[a][t].z));
-                acc[a][t].w = fmaf(sc, d.w, fmaf(bb, sxv[s].w, acc[a][t].w));
-              }
-            }
         }
-      }
     }
   };
 
@@ -292,21 +305,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
       const int tile = tbi * TB + t;
-      if (tile >= p.ntiles) break;                 // uniform
+      if (tile >= ntiles) break;                   // uniform
       if (t > 0) __syncthreads();
 #pragma unroll
       for (int a = 0; a < NA; ++a) *(f32x4*)&red[((wave * NA + a) * 64 + lane) * 4] = acc[a][t];
       __syncthreads();
       if (tid < 256) {
         const int el = tid & 63, r = tid >> 6;
-        const int m = 4 * (el >> 4) + r, n = tile * 16 + (el & 15);
+        const int m = 4 * (el >> 4) + r, n = item_row0(tile) + (el & 15);
+        const bool row_on = true;
         float y0 = 0.f, y1 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           y0 += red[((w * NA + 0) * 64 + el) * 4 + r];
           if constexpr (SWIGLU) y1 += red[((w * NA + 1) * 64 + el) * 4 + r];
         }
-        if (m < p.M && n < p.N) {
+        if (m < p.M && row_on) {
           AT* out = (AT*)p.out;
           if constexpr (SWIGLU) {
             const float gt = (float)(AT)y0, up = (float)(AT)y1;
@@ -389,25 +403,34 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
   stage_x(0, klen0);
   __syncthreads();
   int staged = 0;
+  // with several activation chunks the NEXT chunk's x is fetched into registers while the current
+  // chunk's MFMAs run, so that re-staging costs two barriers but no exposed L2 round trip
+  auto prefetch_next_x = [&](int c, int tbi) {
+    if (nchunks == 1) return;
+    const int nc = (c + 1) % nchunks;
+    if (nc == 0 && tbi + 1 >= nbatch) return;
+    load_x(nc * p.kc, min(p.kc, p.K - nc * p.kc));
+  };
+  prefetch_next_x(0, 0);
 
-  // ================= persistent loop over tile batches
-  for (; tb < nbatch; tb += gridDim.x) {
+  // ================= this workgroup's tile batches
+  for (; tb < nbatch; ++tb) {
     zero_acc();
     for (int c = 0; c < nchunks; ++c) {
       const int cbase = c * p.kc, kend = min(p.K, cbase + p.kc);
       if (staged != c) {
-        load_x(cbase, kend - cbase);
         __syncthreads();                      // every wave is done reading the old fragments
-        stage_x(cbase, kend - cbase);
+        stage_x(cbase, kend - cbase);         // from the registers prefetched one chunk ago
         __syncthreads();
         staged = c;
+        prefetch_next_x(c, tb);
       }
       for (int k0 = cbase; k0 < kend; k0 += KS) {
         // the batch that follows this one in this workgroup's sequence
         int ntb = tb, nk0 = k0 + KS, nkend = kend;
         if (nk0 >= kend) {
           if (c + 1 < nchunks) { nk0 = cbase + p.kc; nkend = min(p.K, cbase + 2 * p.kc); }
-          else if (tb + (int)gridDim.x < nbatch) { ntb = tb + gridDim.x; nk0 = 0; nkend = klen0; }
+          else if (tb + 1 < nbatch) { ntb = tb + 1; nk0 = 0; nkend = klen0; }
           else { nk0 = 0; nkend = 0; }                         // nothing left: issue_u becomes a no-op
         }
         // rolling prefetch: as soon as the MFMAs of slot u have consumed its registers, the same
@@ -442,8 +465,7 @@ int launch_j(const MfmaParams& p, hipStream_t st) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  const int nbatch = (p.ntiles + TB - 1) / TB;
-  const int nwg = std::min(nbatch, n_cu);
+  const int nwg = std::min(p.N / 16, n_cu);        // one workgroup per CU; items are dealt in-kernel
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, p);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -472,6 +494,7 @@ int launch_at(bool q4, const MfmaParams& p, hipStream_t st) {
 // true when the MFMA path can run this call
 bool gemv_mfma_supported(const LinearW& W, const GemvCall& c) {
   if (c.force_v1) return false;
+  if (W.layout != 1) return false;        // the MFMA kernel reads the tile-major layout only (repack.hip)
   if (c.rnd != RND_NONE) return false;
   if (c.M < 1 || c.M > 16) return false;
   if (c.act != MI_BF16 && c.act != MI_F16) return false;
@@ -492,11 +515,11 @@ int launch_gemv_mfma(const LinearW& W, const GemvCall& c, hipStream_t st) {
   p.x = c.x; p.ldx = c.ldx; p.M = c.M; p.pro = c.pro; p.norm_w = c.norm_w; p.eps = c.eps;
   p.w = W.w; p.scales = W.scales; p.biases = W.biases; p.N = (c.epi == EPI_SWIGLU) ? c.pair_offset : W.N; p.K = W.K;
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
-  p.ntiles = p.N / 16;
   // activation chunk held in LDS as fragments: whole K up to 6144 (M <= 8) / 4096 (M <= 16),
   // else chunks of 4096 (a multiple of every batch span and of the int4 block)
   const int kc_max = c.M <= 8 ? 6144 : 4096;
   p.kc = (W.K <= kc_max) ? W.K : 4096;
+  p.layout = W.layout;
   p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;
   p.lora_b0 = W.lora_b[0]; p.lora_b1 = W.lora_b[1];
   p.lora_row0_0 = W.lora_row0[0]; p.lora_n_0 = W.lora_n[0]; p.lora_rank_0 = W.lora_rank[0]; p.lora_scale_0 = W.lora_scale[0];

@@ -32,7 +32,7 @@ struct GemvParams {
   const void* x; int ldx; int M;
   int rnd; int pro; const void* norm_w; float eps;
   const void* w; const void* scales; const void* biases;
-  int N, K, group;
+  int N, K, group, layout;
   int epi; void* out; int ldo; void* resid; int pair_offset;
   int npairs;
   // LoRA
@@ -52,12 +52,14 @@ __device__ __forceinline__ void load8(const GemvParams& p, int row, int kb, floa
     f32x4 b = __builtin_nontemporal_load((const f32x4*)(base + 4));
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
   } else if constexpr (WK == WK_BF16) {
-    const uint16_t* base = (const uint16_t*)p.w + (size_t)row * p.K + kb;
+    const uint16_t* base = p.layout ? (const uint16_t*)((const char*)p.w + tiled_piece_dense16(row, kb, p.K))
+                                    : (const uint16_t*)p.w + (size_t)row * p.K + kb;
     u32x4 v = __builtin_nontemporal_load((const u32x4*)base);
     o[0] = bf16lo(v.x); o[1] = bf16hi(v.x); o[2] = bf16lo(v.y); o[3] = bf16hi(v.y);
     o[4] = bf16lo(v.z); o[5] = bf16hi(v.z); o[6] = bf16lo(v.w); o[7] = bf16hi(v.w);
   } else if constexpr (WK == WK_F16) {
-    const f16* base = (const f16*)p.w + (size_t)row * p.K + kb;
+    const f16* base = p.layout ? (const f16*)((const char*)p.w + tiled_piece_dense16(row, kb, p.K))
+                               : (const f16*)p.w + (size_t)row * p.K + kb;
     u32x4 v = __builtin_nontemporal_load((const u32x4*)base);
     const f16* h = (const f16*)&v;
 #pragma unroll
@@ -68,11 +70,18 @@ __device__ __forceinline__ void load8(const GemvParams& p, int row, int kb, floa
     const int ng = p.K / p.group;
     const size_t gi = (size_t)row * ng + kb / p.group;
     float s, b;
-    if constexpr (SDT == 0) { s = ((const float*)p.scales)[gi]; b = ((const float*)p.biases)[gi]; }
+    const char* blk = nullptr;
+    if (BITS == 4 && SDT != 0 && p.layout) {       // tile-major int4 (repack.hip): scales live in the block
+      blk = (const char*)p.w + tiled_block_q4(row, kb, p.K);
+      const int so = tiled_q4_scale_off(row, kb);
+      if constexpr (SDT == 1) { s = (float)*(const bf16*)(blk + so); b = (float)*(const bf16*)(blk + so + 64); }
+      else { s = (float)*(const f16*)(blk + so); b = (float)*(const f16*)(blk + so + 64); }
+    } else if constexpr (SDT == 0) { s = ((const float*)p.scales)[gi]; b = ((const float*)p.biases)[gi]; }
     else if constexpr (SDT == 1) { s = (float)((const bf16*)p.scales)[gi]; b = (float)((const bf16*)p.biases)[gi]; }
     else { s = (float)((const f16*)p.scales)[gi]; b = (float)((const f16*)p.biases)[gi]; }
     if constexpr (BITS == 4) {
-      const uint32_t* base = (const uint32_t*)p.w + (size_t)row * (p.K / 8) + kb / 8;
+      const uint32_t* base = blk ? (const uint32_t*)(blk + tiled_q4_code_off(row, kb))
+                                 : (const uint32_t*)p.w + (size_t)row * (p.K / 8) + kb / 8;
       uint32_t v = __builtin_nontemporal_load(base);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = mul_add_unfused((float)((v >> (4 * j)) & 15u), s, b);
@@ -336,7 +345,7 @@ int launch_wk(int wk, const GemvParams& p, hipStream_t st) {
 GemvParams make_params(const LinearW& W, const GemvCall& c) {
   GemvParams p{};
   p.x = c.x; p.ldx = c.ldx; p.M = c.M; p.rnd = c.rnd; p.pro = c.pro; p.norm_w = c.norm_w; p.eps = c.eps;
-  p.w = W.w; p.scales = W.scales; p.biases = W.biases; p.N = W.N; p.K = W.K; p.group = W.group;
+  p.w = W.w; p.scales = W.scales; p.biases = W.biases; p.N = W.N; p.K = W.K; p.group = W.group; p.layout = W.layout;
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
   p.npairs = (c.epi == EPI_SWIGLU) ? c.pair_offset : (W.N + 1) / 2;
   p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;

@@ -11,6 +11,8 @@ struct LinearW {
   const void* scales = nullptr;  // [N][K/group] in the scale dtype
   const void* biases = nullptr;
   int N = 0, K = 0, group = 64;
+  int layout = 0;              // 0 = row-major (checkpoint order); 1 = tile-major (repack.hip); then
+                               // `w` is the single tiled buffer (int4: scales/biases live inside it)
   // LoRA (mlx-lm LoRALinear): rows [lora_row0, lora_row0+lora_n) of this (fused) matrix get
   // + scale * ((x A) B); A [K][r], B [r][lora_n] stored as float32.
   const float* lora_a[2] = {nullptr, nullptr};
@@ -47,6 +49,27 @@ struct GemvCall {
 };
 
 int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
+
+// tile-major weight layout (repack.hip)
+bool tiled_supported(int wk, int N, int K, int group);
+size_t tiled_bytes(int wk, int N, int K);
+int launch_repack_tiled(const LinearW& src_row_major, void* dst, hipStream_t st);
+
+// byte offset of the 16-byte piece holding W[row][k .. k+8) (k % 8 == 0) of a tile-major dense matrix
+__host__ __device__ inline size_t tiled_piece_dense16(size_t row, int k, int K) {
+  return (((row >> 4) * (size_t)(K / 32) + (size_t)(k >> 5)) * 64 + (size_t)(((k >> 3) & 3) * 16 + (int)(row & 15))) * 16;
+}
+// tile-major int4: byte offset of the block of (row, k), of the dword holding codes k..k+8, and of the scale / bias
+__host__ __device__ inline size_t tiled_block_q4(size_t row, int k, int K) {
+  return ((row >> 4) * (size_t)(K / 128) + (size_t)(k >> 7)) * 1152;
+}
+__host__ __device__ inline int tiled_q4_code_off(size_t row, int k) {   // within the block, bytes
+  const int dd = (k >> 3) & 15;
+  return (((dd >> 2) * 16 + (int)(row & 15)) * 4 + (dd & 3)) * 4;
+}
+__host__ __device__ inline int tiled_q4_scale_off(size_t row, int k) {  // + 64 for the bias
+  return 1024 + (int)(row & 15) * 4 + ((k >> 6) & 1) * 2;
+}
 // t[m][slot][j] = round(sum_k x[m][k] A[k][j]) for the adapted ranges of W (same prologue as the gemv)
 int launch_lora_down(const LinearW& W, const GemvCall& c, float* t, int t_ld, hipStream_t st);
 

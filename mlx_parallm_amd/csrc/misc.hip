@@ -16,19 +16,33 @@ __global__ __launch_bounds__(256) void embed_kernel(LinearW W, EmbedCall c) {
   AT* out = (AT*)c.out + (size_t)row * W.K;
   for (int k = threadIdx.x; k < W.K; k += 256) {
     float v;
+    const int k8 = k & ~7;
     if constexpr (WK == WK_F32) v = ((const float*)W.w)[(size_t)tok * W.K + k];
-    else if constexpr (WK == WK_BF16) v = (float)((const bf16*)W.w)[(size_t)tok * W.K + k];
-    else if constexpr (WK == WK_F16) v = (float)((const f16*)W.w)[(size_t)tok * W.K + k];
+    else if constexpr (WK == WK_BF16)
+      v = W.layout ? (float)((const bf16*)((const char*)W.w + tiled_piece_dense16(tok, k8, W.K)))[k & 7]
+                   : (float)((const bf16*)W.w)[(size_t)tok * W.K + k];
+    else if constexpr (WK == WK_F16)
+      v = W.layout ? (float)((const f16*)((const char*)W.w + tiled_piece_dense16(tok, k8, W.K)))[k & 7]
+                   : (float)((const f16*)W.w)[(size_t)tok * W.K + k];
     else {
       constexpr int BITS = (WK >= WK_Q8_F32) ? 8 : 4;
       constexpr int SDT = (WK - 3) % 3;
       constexpr int PER = 32 / BITS;
       const size_t gi = (size_t)tok * (W.K / W.group) + k / W.group;
       float s, b;
+      uint32_t word;
+      if (BITS == 4 && SDT != 0 && W.layout) {     // tile-major int4 (repack.hip)
+        const char* blk = (const char*)W.w + tiled_block_q4(tok, k, W.K);
+        const int so = tiled_q4_scale_off(tok, k);
+        if constexpr (SDT == 1) { s = (float)*(const bf16*)(blk + so); b = (float)*(const bf16*)(blk + so + 64); }
+        else { s = (float)*(const f16*)(blk + so); b = (float)*(const f16*)(blk + so + 64); }
+        word = *(const uint32_t*)(blk + tiled_q4_code_off(tok, k8));
+      } else {
       if constexpr (SDT == 0) { s = ((const float*)W.scales)[gi]; b = ((const float*)W.biases)[gi]; }
       else if constexpr (SDT == 1) { s = (float)((const bf16*)W.scales)[gi]; b = (float)((const bf16*)W.biases)[gi]; }
       else { s = (float)((const f16*)W.scales)[gi]; b = (float)((const f16*)W.biases)[gi]; }
-      const uint32_t word = ((const uint32_t*)W.w)[(size_t)tok * (W.K / PER) + k / PER];
+      word = ((const uint32_t*)W.w)[(size_t)tok * (W.K / PER) + k / PER];
+      }
       const float q = (float)((word >> (BITS * (k % PER))) & ((1u << BITS) - 1u));
       v = mul_add_unfused(q, s, b);
     }

@@ -28,6 +28,7 @@ LinearW to_linear(const mi_op_linear* w) {
   LinearW W;
   W.wk = w->wk; W.w = w->w; W.scales = w->scales; W.biases = w->biases; W.N = w->N; W.K = w->K;
   W.group = w->group > 0 ? w->group : 64;
+  W.layout = w->layout;
   return W;
 }
 
@@ -80,6 +81,18 @@ int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters,
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a) {
   if (!w || !a) return 0;
   return gemv_mfma_supported(to_linear(w), to_call(a)) ? 1 : 0;
+}
+
+uint64_t mi_op_tiled_bytes(const mi_op_linear* w) {
+  if (!w || !tiled_supported(w->wk, w->N, w->K, w->group > 0 ? w->group : 64)) return 0;
+  return (uint64_t)tiled_bytes(w->wk, w->N, w->K);
+}
+
+int mi_op_repack_tiled(const mi_op_linear* w, void* dst) {
+  if (!w || !dst) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  MI_TRY(launch_repack_tiled(to_linear(w), dst, nullptr));
+  return finish();
 }
 
 int mi_op_embed(const mi_op_linear* w, const int32_t* tokens, int rows, int act, int rnd, void* out) {

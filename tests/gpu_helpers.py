@@ -46,6 +46,20 @@ def op_linear(kind: str, N: int, K: int, w, scales=None, biases=None, group: int
     return ol
 
 
+def to_tiled(ol: L.OpLinear, keep: list) -> bool:
+    """Repack a row-major op_linear into the tile-major layout in place (the tiled buffer is appended
+    to `keep`).  Returns False when the matrix is not eligible (then it stays row-major)."""
+    nbytes = int(L.lib().mi_op_tiled_bytes(C.byref(ol)))
+    if nbytes == 0:
+        return False
+    dst = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    L.check(L.lib().mi_op_repack_tiled(C.byref(ol), C.c_void_p(dst.data_ptr())))
+    keep.append(dst)
+    ol.w, ol.scales, ol.biases, ol.layout = dst.data_ptr(), 0, 0, 1
+    return True
+
+
 def gemv(ol: L.OpLinear, x, M, act, *, rnd=0, pro=0, norm_w=None, eps=0.0, epi=0, out=None, ldo=0, resid=None,
          pair_offset=0, force_generic=0, ldx=None):
     a = L.OpGemvArgs()

@@ -22,7 +22,16 @@ def main():
     ap.add_argument("--quant", type=int, default=0)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--generic", type=int, default=0)
+    ap.add_argument("--tiled", type=int, default=1)
+    ap.add_argument("--lib", default=None, help="A/B: load this build of libmi355_decode.so instead")
     args = ap.parse_args()
+    if args.lib:
+        L.LIB_PATH = Path(args.lib)
+        old_sig = dict(L.SIGNATURES)
+        probe = C.CDLL(args.lib)
+        L.SIGNATURES = {k: v for k, v in old_sig.items() if hasattr(probe, k)}
+        if "mi_op_tiled_bytes" not in L.SIGNATURES:
+            args.tiled = 0
     H, I, QD, KVD, V = {"mistral-7b": (4096, 14336, 4096, 1024, 32000), "qwen3-14b": (5120, 17408, 5120, 1024, 151936)}[args.model]
     B = args.batch
     dev = "cuda"
@@ -44,6 +53,13 @@ def main():
             ol.w = w.data_ptr()
             wbytes = w.numel() * 2
         ol.N, ol.K, ol.group = N, K, 64
+        if args.tiled:
+            nbytes = int(L.lib().mi_op_tiled_bytes(C.byref(ol)))
+            dst = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            L.check(L.lib().mi_op_repack_tiled(C.byref(ol), C.c_void_p(dst.data_ptr())))
+            keep.append(dst)
+            ol.w, ol.scales, ol.biases, ol.layout = dst.data_ptr(), 0, 0, 1
         x = torch.randn((B, K), device=dev, dtype=torch.float32).to(torch.bfloat16)
         nw = torch.ones(K, device=dev, dtype=torch.bfloat16)
         n_out = N // 2 if epi == L.EPI_SWIGLU else N
