@@ -80,7 +80,7 @@ __device__ __forceinline__ void raw_to_f32(const uint32_t (&r)[NW32], float (&o)
 }
 
 // D must be a multiple of 32 for 16-bit caches (two elements per dword per lane); float caches any D % 16 == 0
-template <typename T, int D, int G>
+template <typename T, int D, int G, bool NORM>
 __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
   constexpr int EPL = D / 16, NWV = 8, U = 8;
   constexpr int NW32 = EPL * (int)sizeof(T) / 4;
@@ -124,22 +124,32 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
   };
   if (s0 < send) issue_kv(s0);
 
-  // ---- prologue: this lane's pieces of q (G heads), k_new, v_new; norm + RoPE in registers
+  // ---- prologue: this lane's pieces of q (G heads), k_new, v_new; norm + RoPE in registers.
+  // Every load is issued before the first use (straight-line code: a load under a branch costs a
+  // vmcnt(0) drain of the K/V rows already in flight and a serialized L2 round trip each).
   const bool hi = li >= 8;                       // this lane holds the second half of a RoPE pair
-  float cs[EPL], sn[EPL];
+  uint32_t qraw[G][NW32], kraw[NW32], vnr[NW32];
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    const int i = (li & 7) * EPL + e;
-    cs[e] = c.cos_tab[(size_t)pos * (D / 2) + i];
-    sn[e] = c.sin_tab[(size_t)pos * (D / 2) + i];
+  for (int g = 0; g < G; ++g) load_raw<NW32>(row + (size_t)(kh * G + g) * D + li * EPL, qraw[g]);
+  load_raw<NW32>(row + nq + (size_t)kh * D + li * EPL, kraw);
+  load_raw<NW32>(row + nq + (size_t)(s.Hkv + kh) * D + li * EPL, vnr);
+  float cs[EPL], sn[EPL];
+  {
+    const float* cp = c.cos_tab + (size_t)pos * (D / 2) + (li & 7) * EPL;
+    const float* sp = c.sin_tab + (size_t)pos * (D / 2) + (li & 7) * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { cs[e] = cp[e]; sn[e] = sp[e]; }
   }
-  auto load_piece = [&](const T* p, float (&x)[EPL]) {
-    uint32_t r[NW32];
-    load_raw<NW32>(p, r);
-    raw_to_f32<T, EPL, NW32>(r, x);
-  };
-  auto norm_rope = [&](float (&x)[EPL], const T* nw) {
-    if (nw != nullptr) {
+  float qnw[EPL], knw[EPL];
+  if constexpr (NORM) {
+    uint32_t r0[NW32], r1[NW32];
+    load_raw<NW32>((const T*)c.q_norm_w + li * EPL, r0);
+    load_raw<NW32>((const T*)c.k_norm_w + li * EPL, r1);
+    raw_to_f32<T, EPL, NW32>(r0, qnw);
+    raw_to_f32<T, EPL, NW32>(r1, knw);
+  }
+  auto norm_rope = [&](float (&x)[EPL], const float (&nw)[EPL]) {
+    if constexpr (NORM) {
       float ss = 0.f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) ss = fmaf(x[e], x[e], ss);
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
       const float rs = 1.0f / sqrtf(ss / (float)D + c.eps);
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
-        x[e] = to_f32(store_act<T>(to_f32(store_act<T>(x[e] * rs, s.rnd)) * (float)nw[li * EPL + e], s.rnd));
+        x[e] = to_f32(store_act<T>(to_f32(store_act<T>(x[e] * rs, s.rnd)) * nw[e], s.rnd));
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -173,17 +183,16 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     float x[EPL];
-    load_piece(row + (size_t)(kh * G + g) * D + li * EPL, x);
-    norm_rope(x, (const T*)c.q_norm_w);
+    raw_to_f32<T, EPL, NW32>(qraw[g], x);
+    norm_rope(x, qnw);
     pack(x, qr[g]);
   }
-  uint32_t knr[NW32], vnr[NW32];
+  uint32_t knr[NW32];
   {
     float x[EPL];
-    load_piece(row + nq + (size_t)kh * D + li * EPL, x);
-    norm_rope(x, (const T*)c.k_norm_w);
+    raw_to_f32<T, EPL, NW32>(kraw, x);
+    norm_rope(x, knw);
     pack(x, knr);
-    load_raw<NW32>(row + nq + (size_t)(s.Hkv + kh) * D + li * EPL, vnr);
   }
   if (owner && wave == 0 && gq == 0 && pos < s.cap) {
 #pragma unroll
@@ -305,26 +314,27 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
     if (c.nsplit == 1) {
       out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
     } else {
+      // partials are published with write-through (sc1) stores and read back with sc1 loads: no
+      // release / acquire fence is needed (an agent release fence here writes back the whole XCD
+      // L2 and was measured at ~8 us per launch with the previous kernel's output still dirty)
       float* pp = c.partial + (((size_t)b * s.Hq + h) * c.nsplit + split) * (D + 2);
-      pp[2 + d] = O;
-      if (d == 0) { pp[0] = mn; pp[1] = L; }
+      __hip_atomic_store(&pp[2 + d], O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == 0) {
+        __hip_atomic_store(&pp[0], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pp[1], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
-  if (c.nsplit == 1) return;
+  if (c.nsplit == 1 || c.counters == nullptr) return;    // (counters == nullptr: timing experiments only)
 
-  // ---- publish, take a ticket; the last split of this (b, kv-head) combines
+  // ---- every storing wave drains its stores, the workgroup meets, ONE lane takes a ticket; the
+  // workgroup that draws the last ticket of this (b, kv-head) combines (it waits for nobody)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(&c.counters[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == c.nsplit - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&c.counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
+    if (last) __hip_atomic_store(&c.counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     is_last_sh = last;
   }
   __syncthreads();
@@ -333,31 +343,41 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
     const int g = idx / D, d = idx % D, h = kh * G + g;
     const float* pp = c.partial + ((size_t)b * s.Hq + h) * c.nsplit * (D + 2);
     float mn = -1e30f;
-    for (int i = 0; i < c.nsplit; ++i) mn = fmaxf(mn, pp[i * (D + 2)]);
+    for (int i = 0; i < c.nsplit; ++i) mn = fmaxf(mn, __hip_atomic_load(&pp[i * (D + 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     float L = 0.f, O = 0.f;
     for (int i = 0; i < c.nsplit; ++i) {
-      const float cw = __builtin_amdgcn_exp2f(pp[i * (D + 2)] - mn);
-      L = fmaf(pp[i * (D + 2) + 1], cw, L);
-      O = fmaf(pp[i * (D + 2) + 2 + d], cw, O);
+      const float mi_ = __hip_atomic_load(&pp[i * (D + 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float li_ = __hip_atomic_load(&pp[i * (D + 2) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float oi_ = __hip_atomic_load(&pp[i * (D + 2) + 2 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float cw = __builtin_amdgcn_exp2f(mi_ - mn);
+      L = fmaf(li_, cw, L);
+      O = fmaf(oi_, cw, O);
     }
     out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
   }
 }
 
-template <typename T, int D>
-int launch_g(const AttnDecodeCall& c, hipStream_t st) {
+template <typename T, int D, bool NORM>
+int launch_gn(const AttnDecodeCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
   switch (s.Hq / s.Hkv) {
-    case 1: hipLaunchKernelGGL((attn_decode_kernel<T, D, 1>), grid, block, 0, st, c); break;
-    case 2: hipLaunchKernelGGL((attn_decode_kernel<T, D, 2>), grid, block, 0, st, c); break;
-    case 4: hipLaunchKernelGGL((attn_decode_kernel<T, D, 4>), grid, block, 0, st, c); break;
-    case 5: hipLaunchKernelGGL((attn_decode_kernel<T, D, 5>), grid, block, 0, st, c); break;
-    case 8: hipLaunchKernelGGL((attn_decode_kernel<T, D, 8>), grid, block, 0, st, c); break;
+    case 1: hipLaunchKernelGGL((attn_decode_kernel<T, D, 1, NORM>), grid, block, 0, st, c); break;
+    case 2: hipLaunchKernelGGL((attn_decode_kernel<T, D, 2, NORM>), grid, block, 0, st, c); break;
+    case 4: hipLaunchKernelGGL((attn_decode_kernel<T, D, 4, NORM>), grid, block, 0, st, c); break;
+    case 5: hipLaunchKernelGGL((attn_decode_kernel<T, D, 5, NORM>), grid, block, 0, st, c); break;
+    case 8: hipLaunchKernelGGL((attn_decode_kernel<T, D, 8, NORM>), grid, block, 0, st, c); break;
     default: return fail(MI_ERR_UNSUPPORTED, "attention: Hq/Hkv must be 1, 2, 4, 5 or 8");
   }
   MI_HIP(hipGetLastError());
   return MI_OK;
+}
+
+template <typename T, int D>
+int launch_g(const AttnDecodeCall& c, hipStream_t st) {
+  const bool norm = c.q_norm_w != nullptr && c.k_norm_w != nullptr;
+  if ((c.q_norm_w != nullptr) != (c.k_norm_w != nullptr)) return fail(MI_ERR_INVALID, "attention_decode: q_norm and k_norm must come together");
+  return norm ? launch_gn<T, D, true>(c, st) : launch_gn<T, D, false>(c, st);
 }
 
 template <typename T>
@@ -384,7 +404,7 @@ bool attention_decode_supported(const AttnShape& s) {
 int launch_attention_decode(const AttnDecodeCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   if (!attention_decode_supported(s)) return fail(MI_ERR_UNSUPPORTED, "attention_decode: shape / dtype not supported");
-  if (c.nsplit < 1 || (c.nsplit > 1 && (c.partial == nullptr || c.counters == nullptr)))
+  if (c.nsplit < 1 || (c.nsplit > 1 && c.partial == nullptr))
     return fail(MI_ERR_INVALID, "attention_decode: bad split configuration");
   if (s.act == MI_F32) return launch_d<float>(c, st);
   if (s.act == MI_BF16) return launch_d<bf16>(c, st);
