@@ -272,11 +272,22 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
 // y = W x for `rows` rows, split into launches of at most 16 (MFMA) / 8 (generic) rows
 int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_t es_in, size_t es_out,
               const char* prof) {
-  Prof pr(e, prof);
   c.force_v1 = e->opt_force_v1;
   const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
   GemvCall probe = c; probe.M = (int)std::min<size_t>(rows, 16);
-  const size_t step = gemv_mfma_supported(f.W, probe) ? 16 : 8;
+  const bool mfma = gemv_mfma_supported(f.W, probe);
+  const size_t step = mfma ? 16 : 8;
+  // measurement: the MFMA kernel is stamped with its own dispatch begin/end (hipExtLaunchKernelGGL);
+  // other paths are bracketed with events on the stream
+  const bool selected = !e->prof_name.empty() && e->prof_name == prof;
+  const bool stamp = selected && mfma && rows <= step;
+  Prof pr(e, stamp ? "" : prof);
+  if (stamp) {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipEventCreate(&a); hipEventCreate(&b);
+    c.ev_start = a; c.ev_stop = b;
+    e->prof_events.emplace_back(a, b);
+  }
   const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
   for (size_t r = 0; r < rows; r += step) {
     GemvCall cc = c;

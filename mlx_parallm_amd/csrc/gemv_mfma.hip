@@ -17,6 +17,8 @@
 // the four waves split K round-robin in 32-wide (dense) or 128-wide (int4) blocks, so that one
 // step of the workgroup reads 256 contiguous bytes of each weight row; partial tiles are
 // summed through LDS.  Activations are staged (RMSNorm applied) as 16-bit MFMA A-fragments.
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -451,6 +453,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
   }
 }
 
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
 template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
 int launch_j(const MfmaParams& p, hipStream_t st) {
   auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU, NW, J>;
@@ -466,7 +470,10 @@ int launch_j(const MfmaParams& p, hipStream_t st) {
     if (n_cu <= 0) n_cu = 256;
   }
   const int nwg = std::min(p.N / 16, n_cu);        // one workgroup per CU; items are dealt in-kernel
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, p);
+  if (g_ev_start != nullptr)   // measurement: dispatch-level begin/end timestamps of THIS kernel
+    hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, g_ev_start, g_ev_stop, 0, p);
+  else
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, p);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -524,8 +531,10 @@ int launch_gemv_mfma(const LinearW& W, const GemvCall& c, hipStream_t st) {
   p.lora_b0 = W.lora_b[0]; p.lora_b1 = W.lora_b[1];
   p.lora_row0_0 = W.lora_row0[0]; p.lora_n_0 = W.lora_n[0]; p.lora_rank_0 = W.lora_rank[0]; p.lora_scale_0 = W.lora_scale[0];
   p.lora_row0_1 = W.lora_row0[1]; p.lora_n_1 = W.lora_n[1]; p.lora_rank_1 = W.lora_rank[1]; p.lora_scale_1 = W.lora_scale[1];
-  if (c.act == MI_BF16) return launch_at<bf16>(q4, p, st);
-  return launch_at<f16>(q4, p, st);
+  g_ev_start = (hipEvent_t)c.ev_start; g_ev_stop = (hipEvent_t)c.ev_stop;
+  const int rc = (c.act == MI_BF16) ? launch_at<bf16>(q4, p, st) : launch_at<f16>(q4, p, st);
+  g_ev_start = g_ev_stop = nullptr;
+  return rc;
 }
 
 }  // namespace mi

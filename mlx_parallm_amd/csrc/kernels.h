@@ -46,6 +46,8 @@ struct GemvCall {
   const float* lora_t = nullptr;  // [M][2][max_rank] = round(x A) for the (up to 2) adapted row ranges
   int lora_t_ld = 0;
   int force_v1 = 0;
+  void* ev_start = nullptr;       // measurement: hipEvent_t pair stamped with this kernel's own begin / end
+  void* ev_stop = nullptr;        // (hipExtLaunchKernelGGL); MFMA path only
 };
 
 int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
