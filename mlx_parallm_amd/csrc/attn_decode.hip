@@ -26,14 +26,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// all-reduce over the 16 lanes of a DPP row (row_ror:8,4,2,1)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_amdgcn_update_dpp(0.f, v, 0x128, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0.f, v, 0x124, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0.f, v, 0x122, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0.f, v, 0x121, 0xf, 0xf, false);
-  return v;
-}
 __device__ __forceinline__ float row16_ror8(float v) { return __builtin_amdgcn_update_dpp(0.f, v, 0x128, 0xf, 0xf, false); }
 
 template <typename T>

@@ -77,10 +77,30 @@ struct alignas(16) u128 { uint32_t x, y, z, w; };
 __device__ __forceinline__ float bf16lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums without LDS traffic: __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round
+// trip of ~100+ cycles per step, and the steps of a butterfly are dependent); DPP row rotations are
+// plain VALU modifiers.  row16_sum: all-reduce over the 16 lanes of a DPP row.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x124, 0xf, 0xf, false);   // row_ror:4
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x122, 0xf, 0xf, false);   // row_ror:2
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x121, 0xf, 0xf, false);   // row_ror:1
   return v;
+}
+// all-reduce over aligned groups of 8 lanes: quad xor-1, quad xor-2, then mirror inside the half row
+__device__ __forceinline__ float lane8_sum(float v) {
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
   constexpr int NA = SWIGLU ? 2 : 1;
   constexpr int BK = Q4 ? 128 : 32;      // k covered by one 16-byte load of the 4 lane groups
   constexpr int UK = Q4 ? (32 / NW) : (128 / NW) / NA;   // loads per wave per tile per weight stream per batch
-  constexpr int TB = Q4 ? 2 : 1;         // tiles per batch
+  constexpr int TB = (Q4 && !SWIGLU) ? 2 : 1;   // tiles per batch (int4: 8 weight loads per wave per batch either way)
   constexpr int KS = NW * UK * BK;       // k-span of a batch (4096 dense / 2048 SwiGLU / 4096 int4)
   // J = staging items per thread per activation row: 1 covers kc <= 8*NT (4096), 2 up to 8192
   using S = AT;                          // scale dtype == activation dtype on this path
@@ -228,9 +228,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
           frag[frag_slot<Q4>(k8, m, MB)] = v;
           if constexpr (Q4) {
             // 8 consecutive lanes hold the 8 pieces of one 64-wide quantisation group
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 4, 64);
+            sum = lane8_sum(sum);
             if ((k8 & 7) == 0) sx[(k8 >> 3) * MB + m] = sum;
           }
         }
@@ -459,7 +457,7 @@ template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
 int launch_j(const MfmaParams& p, hipStream_t st) {
   auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU, NW, J>;
   constexpr int NA = SWIGLU ? 2 : 1;
-  constexpr int TB = Q4 ? 2 : 1;
+  constexpr int TB = (Q4 && !SWIGLU) ? 2 : 1;
   const size_t lds = (size_t)p.kc * MB * 2 + (Q4 ? (size_t)(p.kc / 64) * MB * 4 : 0) +
                      (size_t)NW * NA * 64 * 4 * 4 + 16 * 4 + (size_t)NW * 16 * 4;
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
