@@ -95,6 +95,8 @@ struct mi_engine {
   int opt_force_v1 = 0;
   int opt_fused_attn = 1;
   int opt_tile_weights = 1;
+  int opt_prefill_gemm = 1;
+  void* xn = nullptr;            // [rows][max(H, I)] normalised activations of the prefill GEMMs
 };
 
 struct mi_kv {
@@ -230,6 +232,8 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
     MI_HIP(hipMalloc(&e->attn, rows * (size_t)d.num_heads * d.head_dim * es));
     MI_HIP(hipMalloc(&e->act, rows * (size_t)d.intermediate_size * es));
     MI_HIP(hipMalloc(&e->lora_t, rows * 2 * 64 * sizeof(float)));
+    hipFree(e->xn);
+    MI_HIP(hipMalloc(&e->xn, rows * (size_t)d.hidden_size * es));
     e->ws_rows = rows;
   }
   if (logit_rows > e->ws_logit_rows) {
@@ -273,6 +277,15 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
 int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_t es_in, size_t es_out,
               const char* prof) {
   c.force_v1 = e->opt_force_v1;
+  if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {
+    // prefill: one MFMA tile GEMM over all rows (the RMSNorm runs as its own row-wise kernel)
+    Prof pr(e, prof);
+    if (c.pro == PRO_NORM) {
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream));
+      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+    }
+    return launch_gemm_prefill(f.W, c, rows, e->stream);
+  }
   const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
   GemvCall probe = c; probe.M = (int)std::min<size_t>(rows, 16);
   const bool mfma = gemv_mfma_supported(f.W, probe);
@@ -500,7 +513,7 @@ void mi_engine_destroy(mi_engine* e) {
     hipFree(l.in_norm); hipFree(l.post_norm); hipFree(l.q_norm); hipFree(l.k_norm);
     hipFree(l.in_norm32); hipFree(l.post_norm32); hipFree(l.q_norm32); hipFree(l.k_norm32);
   }
-  hipFree(e->final_norm32);
+  hipFree(e->final_norm32); hipFree(e->xn);
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t);
@@ -808,6 +821,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   const std::string k(key);
   if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
   if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
+  if (k == "prefill_gemm") { e->opt_prefill_gemm = value != 0; return MI_OK; }
   if (k == "tile_weights") {
     if (e->finalized) return fail(MI_ERR_INVALID, "tile_weights must be set before mi_engine_finalize");
     e->opt_tile_weights = value != 0; return MI_OK;

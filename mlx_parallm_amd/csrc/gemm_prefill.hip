@@ -1,0 +1,250 @@
+// gemm_prefill.hip -- MFMA tile GEMM for the prefill call of generate_step (L > 1 tokens per row):
+//   C[M][N] = X[M][K] . W[N][K]^T   (nn.Linear on (B, L, H) activations: llama.py:93,143,165)
+// plus the row-wise RMSNorm that feeds it (llama.py:187,189) and the residual / SwiGLU epilogues.
+// 16-bit activations, dense 16-bit weights in the tile-major layout of repack.hip.  The decode
+// kernels (gemv_mfma.hip) stream W once per <= 16 rows; here a 128 x 128 output tile re-uses
+// every weight fragment over 128 rows, which makes the call MFMA-bound instead of HBM-bound.
+//
+// Block = 256 threads = 4 waves as 2 (M) x 2 (N); wave tile 64 x 64 = 4 x 4 MFMA tiles
+// (v_mfma_f32_16x16x32, 64 accumulator registers); K step 64.
+//   * X tile (128 x 64) goes global -> registers -> LDS, rows padded to 144 B so that the 16 lanes
+//     of an A-fragment read (16 consecutive rows, one 16-B chunk each) hit 16 distinct bank groups;
+//     double-buffered, the next tile's global loads are issued before the current tile's MFMAs.
+//   * W fragments come straight from global memory in MFMA order: in the tile-major layout the
+//     fragment of (16 rows, 32 k) is one contiguous KiB, lane l at 16 l -- no LDS, no transpose.
+//     The next step's 8 fragments are prefetched into a second register set.
+//   * SwiGLU: a wave's four N tiles are two gate tiles and the two matching up tiles, so
+//     silu(gate) * up happens in registers.
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace mi {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDA = 72;   // LDS row stride in elements (144 B)
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (std::is_same<T, bf16>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+struct GemmParams {
+  const void* x; int ldx; int M;
+  const void* w; int N, K;          // W tile-major; N = rows of W (SWIGLU: gate rows = N/2)
+  int epi; void* out; int ldo; void* resid; int pair_offset;
+};
+
+// grid: (n blocks, m blocks).  SWIGLU: a block covers 64 gate columns + the 64 matching up columns.
+template <typename AT, bool SWIGLU>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) AT As[2][BM][LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, g = lane >> 4;
+  // blockIdx.x = M block (fastest): the blocks that run together share one N block, i.e. the same
+  // W tiles, which then stay in the XCD's L2 instead of being re-fetched per block
+  const int bm = blockIdx.x, bn = blockIdx.y;
+  const int m0 = bm * BM;
+  const int nk = p.K / BK;
+  const AT* x = (const AT*)p.x;
+
+  // W tiles (16 rows each) of this wave's four N tiles
+  int wtile[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    if constexpr (!SWIGLU) wtile[nt] = (bn * BN + wn * 64 + nt * 16) / 16;
+    else wtile[nt] = (bn * 64 + wn * 32 + (nt & 1) * 16 + (nt >> 1) * p.pair_offset) / 16;
+  }
+  const int ntiles_w = p.N / 16;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- X tile loads: 128 rows x 8 chunks of 16 B; thread -> chunks tid, tid+256, ...
+  u32x4 areg[4];
+  auto load_a = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
+      const int gm = m0 + row;
+      areg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (gm < p.M) areg[i] = *(const u32x4*)(x + (size_t)gm * p.ldx + ks * BK + kq * 8);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
+      *(u32x4*)&As[buf][row][kq * 8] = areg[i];
+    }
+  };
+  u32x4 breg[3][4][2];     // [set][n tile][k block]; W fragments are fetched two K steps ahead
+  auto load_b = [&](int set, int ks) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int t = min(wtile[nt], ntiles_w - 1);
+        const char* blk = (const char*)p.w + ((size_t)t * (p.K / 32) + (size_t)(ks * 2 + kb)) * 1024;
+        breg[set][nt][kb] = *(const u32x4*)(blk + lane * 16);
+      }
+  };
+
+  load_a(0);
+  load_b(0, 0);
+  if (nk > 1) load_b(1, 1);
+  store_a(0);
+  __syncthreads();
+
+  // the K loop is unrolled by 3 so that the register set of each step is a compile-time index
+  auto step = [&](int ks, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int cur = ks & 1;
+    if (ks + 1 < nk) load_a(ks + 1);
+    if (ks + 2 < nk) load_b((SET + 2) % 3, ks + 2);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      u32x4 af[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = *(const u32x4*)&As[cur][wm * 64 + mt * 16 + c16][kb * 32 + g * 8];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<AT>(af[mt], breg[SET][nt][kb], acc[mt][nt]);
+    }
+    if (ks + 1 < nk) {
+      store_a(cur ^ 1);       // buffer cur^1 was last read one step ago; the barrier of that step separates
+      __syncthreads();
+    }
+  };
+  for (int ks = 0; ks < nk; ks += 3) {
+    step(ks, std::integral_constant<int, 0>{});
+    if (ks + 1 < nk) step(ks + 1, std::integral_constant<int, 1>{});
+    if (ks + 2 < nk) step(ks + 2, std::integral_constant<int, 2>{});
+  }
+
+  // ---- epilogue: lane (c16, g) holds C[m = 4g + r][n = c16] of every 16 x 16 tile
+  AT* out = (AT*)p.out;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 64 + mt * 16 + 4 * g + r;
+      if (m >= p.M) continue;
+      if constexpr (SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = bn * 64 + wn * 32 + j * 16 + c16;
+          if (n >= p.pair_offset) continue;
+          const float gt = (float)(AT)acc[mt][j][r], up = (float)(AT)acc[mt][j + 2][r];
+          const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+          const float sl = (float)(AT)(gt * sig);
+          out[(size_t)m * p.ldo + n] = (AT)(sl * up);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = bn * BN + wn * 64 + nt * 16 + c16;
+          if (n >= p.N) continue;
+          const float y = (float)(AT)acc[mt][nt][r];
+          if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
+          else {
+            AT* h = (AT*)p.resid;
+            h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+          }
+        }
+      }
+    }
+}
+
+// out[row][:] = w * cast_T(x32 * rsqrt(mean(x32^2) + eps))   (nn.RMSNorm); one wave per row
+template <typename AT>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const AT* x, int ldx, const AT* w, AT* out, int ldo,
+                                                           int rows, int H, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const AT* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  for (int k = lane * 8; k < H; k += 512) {
+    const u32x4 v = *(const u32x4*)(xr + k);
+    const AT* e = (const AT*)&v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)e[j]; ss = fmaf(f, f, ss); }
+  }
+  ss = wave_sum(ss);
+  const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+  for (int k = lane * 8; k < H; k += 512) {
+    u32x4 v = *(const u32x4*)(xr + k);
+    const u32x4 wv = *(const u32x4*)(w + k);
+    AT* e = (AT*)&v;
+    const AT* we = (const AT*)&wv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const AT xn = (AT)((float)e[j] * rs);
+      e[j] = (AT)((float)xn * (float)we[j]);
+    }
+    *(u32x4*)(out + (size_t)row * ldo + k) = v;
+  }
+}
+
+}  // namespace
+
+bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
+  if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
+  if (rows < 32) return false;
+  if (!((W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16))) return false;
+  if (W.K % BK != 0 || c.ldx % 8 != 0) return false;
+  if (c.epi == EPI_STORE_F32) return false;
+  if (W.lora_b[0] != nullptr || W.lora_b[1] != nullptr) return false;
+  const int n = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
+  return n % 16 == 0 && (c.epi != EPI_SWIGLU || c.pair_offset % 16 == 0);
+}
+
+int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
+                        hipStream_t st) {
+  if (H % 8 != 0) return fail(MI_ERR_UNSUPPORTED, "rmsnorm_rows: hidden size must be a multiple of 8");
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (act == MI_BF16)
+    hipLaunchKernelGGL(rmsnorm_rows_kernel<bf16>, grid, block, 0, st, (const bf16*)x, ldx, (const bf16*)w, (bf16*)out, ldo, rows, H, eps);
+  else if (act == MI_F16)
+    hipLaunchKernelGGL(rmsnorm_rows_kernel<f16>, grid, block, 0, st, (const f16*)x, ldx, (const f16*)w, (f16*)out, ldo, rows, H, eps);
+  else return fail(MI_ERR_UNSUPPORTED, "rmsnorm_rows: 16-bit activations only");
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// c.pro must be PRO_NONE here (the caller runs launch_rmsnorm_rows first); rows = total rows of x
+int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st) {
+  if (c.pro != PRO_NONE) return fail(MI_ERR_INVALID, "gemm_prefill: normalise the rows first");
+  GemmParams p{};
+  p.x = c.x; p.ldx = c.ldx; p.M = (int)rows; p.w = W.w; p.N = W.N; p.K = W.K;
+  p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
+  const bool sw = c.epi == EPI_SWIGLU;
+  const int ncols = sw ? c.pair_offset : W.N;
+  const dim3 grid(((int)rows + BM - 1) / BM, (ncols + (sw ? 64 : BN) - 1) / (sw ? 64 : BN)), block(256);
+  if (c.act == MI_BF16) {
+    if (sw) hipLaunchKernelGGL((gemm_tile_kernel<bf16, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_tile_kernel<bf16, false>), grid, block, 0, st, p);
+  } else {
+    if (sw) hipLaunchKernelGGL((gemm_tile_kernel<f16, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_tile_kernel<f16, false>), grid, block, 0, st, p);
+  }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+}  // namespace mi

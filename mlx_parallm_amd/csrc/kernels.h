@@ -52,6 +52,12 @@ struct GemvCall {
 
 int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
 
+// prefill (many rows): MFMA tile GEMM + row-wise RMSNorm (gemm_prefill.hip)
+bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows);
+int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st);
+int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
+                        hipStream_t st);
+
 // tile-major weight layout (repack.hip)
 bool tiled_supported(int wk, int N, int K, int group);
 size_t tiled_bytes(int wk, int N, int K);

@@ -163,6 +163,34 @@ def test_fused_and_unfused_decode_attention_agree(tiny_dirs, name):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "qwen3_bf16"])
+def test_prefill_tile_gemm_matches_oracle_and_chunked_path(tiny_dirs, name):
+    """Prefill with enough rows (B*L = 172, not a multiple of the 128-row tile) to take the MFMA tile
+    GEMM (gemm_prefill.hip): all-position logits against the oracle and against the chunked
+    skinny-kernel path, then decode on top of the KV it wrote."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    B, L0 = 4, 43
+    toks = _left_pad_prompts(cfg, B, L0)
+    outs = []
+    for gemm in (1, 0):
+        model.engine.set_option("prefill_gemm", gemm)
+        kv = model.engine.new_kv(B, capacity=64, kv_dtype="model")
+        pre = model.engine.forward(toks, kv, all_positions=True)
+        nxt = model.engine.forward(toks[:, -1:], kv)
+        outs.append((pre, nxt))
+        kv.close()
+    cache = ref.make_cache(B, paged=False)
+    want_pre = ref(toks, cache=cache)
+    want_nxt = ref(toks[:, -1:], cache=cache)[:, -1]
+    tol = 0.1
+    for pre, nxt in outs:
+        assert np.abs(pre - want_pre).max() <= tol, np.abs(pre - want_pre).max()
+        assert np.abs(nxt - want_nxt).max() <= tol
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= tol
+    assert np.mean(np.abs(outs[0][0] - want_pre) > 0.02) < 0.05
+    model.engine.close()
+
+
 def test_generate_step_pipelined_matches_oracle_generate_step(tiny_dirs):
     """utils.generate_step (one-step-ahead pipelining, device-resident token feedback) == the
     oracle's generate_step on the reference's default cache (paged)."""
