@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into the small CSVs kept under profiles/.
+
+  summarize_prof.py stats   <dir> <out.csv> "<header comment>"     (--kernel-trace --stats run)
+  summarize_prof.py pmc     <dir> <COUNTER> <out.csv> "<header comment>"   (--pmc COUNTER run)
+
+Kernel names are shortened: namespaces dropped, the template arguments of the GEMV / GEMM / attention
+kernels spelled out (dtype, weight kind, rows per call, epilogue).
+"""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+_TY = {"DF16b": "bf16", "DF16_": "f16", "f": "float", "i": "int", "j": "uint32"}
+
+
+def _demangle_own(name: str):
+    """rocprofv3's CSV writer leaves some gfx950 names mangled (its demangler does not know the DF16b = __bf16
+    code); this handles the kernels of this library: _ZN2mi12_GLOBAL__N_1<len><name>I<template args>E..."""
+    m = re.match(r"_ZN2mi(?:12_GLOBAL__N_1)?(\d+)", name)
+    if not m:
+        return None
+    ln = int(m.group(1))
+    base = name[m.end():m.end() + ln]
+    rest = name[m.end() + ln:]
+    args = []
+    if rest.startswith("I"):
+        rest = rest[1:]
+        while rest and not rest.startswith("E"):
+            mm = re.match(r"L([bij])(\d+)E", rest)
+            if mm:
+                args.append(("true" if mm.group(2) == "1" else "false") if mm.group(1) == "b" else mm.group(2))
+                rest = rest[mm.end():]
+                continue
+            for code, ty in _TY.items():
+                if rest.startswith(code):
+                    args.append(ty)
+                    rest = rest[len(code):]
+                    break
+            else:
+                return base
+    return base + ("<" + ", ".join(args) + ">" if args else "")
+
+
+def pretty(name: str) -> str:
+    own = _demangle_own(name)
+    if own:
+        name = own.replace("bf16", "__bf16")
+    if "_Accum" in name:   # rocprofv3's failed demangle of a <__bf16, true, ...> instantiation
+        base = name.split("<")[0]
+        return {"gemm_tile_kernel": "gemm_tile_kernel<bf16,swiglu>"}.get(base, base + "<bf16,...>")
+    n = name.replace("void ", "").replace("mi::(anonymous namespace)::", "").replace("mi::", "")
+    n = re.sub(r"\(.*\)$", "", n).replace(" [clone .kd]", "").replace(".kd", "")
+    m = re.match(r"gemv_mfma_kernel<(\w+), (true|false), (\d+), (true|false)(?:, (\d+))?(?:, (\d+))?>", n)
+    if m:
+        at = {"__bf16": "bf16", "_Float16": "f16"}.get(m.group(1), m.group(1))
+        return "gemv_mfma_kernel<%s,%s,MB=%s,%s>" % (at, "int4" if m.group(2) == "true" else "dense", m.group(3),
+                                                      "swiglu" if m.group(4) == "true" else "plain")
+    m = re.match(r"gemm_tile_kernel<(\w+), (true|false)>", n)
+    if m:
+        at = {"__bf16": "bf16", "_Float16": "f16"}.get(m.group(1), m.group(1))
+        return "gemm_tile_kernel<%s,%s>" % (at, "swiglu" if m.group(2) == "true" else "plain")
+    return n.replace("__bf16", "bf16").replace("_Float16", "f16").replace(" ", "")
+
+
+def find(d, suffix):
+    fs = sorted(glob.glob(f"{d}/**/*{suffix}", recursive=True))
+    if not fs:
+        sys.exit(f"no *{suffix} under {d}")
+    return fs
+
+
+def stats(d, out, header):
+    agg = defaultdict(lambda: [0, 0.0])
+    for f in find(d, "_kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            k = pretty(r["Name"])
+            agg[k][0] += int(r["Calls"])
+            agg[k][1] += float(r["TotalDurationNs"])
+    tot = sum(v[1] for v in agg.values())
+    with open(out, "w") as o:
+        for h in header.split("\\n"):
+            o.write(f"# {h}\n")
+        o.write("kernel,calls,total_ms,avg_us,percent\n")
+        for k, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"{k},{c},{ns / 1e6:.3f},{ns / c / 1e3:.2f},{100 * ns / tot:.2f}\n")
+
+
+def pmc(d, counter, out, header):
+    agg = defaultdict(lambda: [0, 0.0])
+    for f in find(d, "_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = pretty(r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+    with open(out, "w") as o:
+        for h in header.split("\\n"):
+            o.write(f"# {h}\n")
+        o.write("kernel,dispatches,avg_KiB_per_dispatch\n" if counter.endswith("_SIZE") else "kernel,dispatches,avg_per_dispatch\n")
+        for k, (c, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"{k},{c},{v / c:.1f}\n")
+
+
+def rename(path):
+    """Re-apply pretty() to the first column of an existing summary (merging rows that collapse)."""
+    lines = open(path).read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if not l.startswith("#")]
+    out = head + [body[0]]
+    for l in body[1:]:
+        k, rest = l.rsplit(",", len(body[0].split(",")) - 1)[0], l.rsplit(",", len(body[0].split(",")) - 1)[1:]
+        out.append(",".join([pretty(k)] + rest))
+    open(path, "w").write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "rename":
+        for f in sys.argv[2:]:
+            rename(f)
+    elif sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    elif sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
+    else:
+        sys.exit(__doc__)
