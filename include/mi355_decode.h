@@ -84,6 +84,9 @@ typedef struct mi_sample_params {
   const float* uniforms;     /* [B] caller-supplied U[0,1) noise, or NULL -> library Philox stream */
   uint64_t seed;             /* Philox key when uniforms == NULL */
   int32_t top_logprobs;      /* 0..MI_MAX_TOP_LOGPROBS: also return the k most likely tokens */
+  int32_t logprobs_at_temperature; /* 0: logprob / top-k logprobs are log_softmax(logits) (generate_step);
+                                    * 1 and temperature > 0: log_softmax(logits / temperature), the distribution
+                                    * the server's logprobs path reports (server/main.py:571-584) */
 } mi_sample_params;
 
 #define MI_MAX_TOP_LOGPROBS 20
@@ -132,6 +135,16 @@ int mi_forward(mi_engine* e, mi_kv* kv, const int32_t* tokens, int B, int L, flo
 int mi_decode_sample(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L,
                      const mi_sample_params* sp, int32_t* tokens_out, float* logprob_out,
                      float* prob_row0_out, int32_t* topk_ids, float* topk_logprobs);
+
+/* Teacher-forced scoring: the all-position logits + log-softmax gather of the server's echo /
+ * perplexity paths (server/main.py:530-557, 646-654), through the KV cache instead of a re-run per
+ * step.  Feeds tokens [B,L] (they are appended to `kv`), then for every position (b,i) reports
+ * log softmax(logits[b,i] (+ logit_bias) (/ temperature if sp->logprobs_at_temperature))[targets[b,i]]
+ * into logprob_out [B*L] (targets < 0: position skipped, 0.0 reported) and, if sp->top_logprobs = k > 0,
+ * the k most likely ids / logprobs of that position into topk_ids / topk_logprobs [B*L,k].
+ * Nothing is sampled; sp->top_p, uniforms and seed are ignored. */
+int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_t* targets, int B, int L,
+                    const mi_sample_params* sp, float* logprob_out, int32_t* topk_ids, float* topk_logprobs);
 
 /* ---- pipelined form of the same step: the reference's one-step-ahead
  *      mx.async_eval(next_y); mx.eval(y) (utils.py:420-427) ----------------------------- */

@@ -41,6 +41,7 @@ class SampleParams(C.Structure):
         ("temperature", C.c_float), ("top_p", C.c_float), ("n_logit_bias", C.c_int32),
         ("logit_bias_ids", C.POINTER(C.c_int32)), ("logit_bias_values", C.POINTER(C.c_float)),
         ("uniforms", C.POINTER(C.c_float)), ("seed", C.c_uint64), ("top_logprobs", C.c_int32),
+        ("logprobs_at_temperature", C.c_int32),
     ]
 
 
@@ -80,6 +81,7 @@ SIGNATURES = {
     "mi_kv_capacity": (C.c_int, [_P]),
     "mi_forward": (C.c_int, [_P, _P, _I32P, C.c_int, C.c_int, _F32P, C.c_int]),
     "mi_decode_sample": (C.c_int, [_P, _P, _I32P, C.c_int, C.c_int, C.POINTER(SampleParams), _I32P, _F32P, _F32P, _I32P, _F32P]),
+    "mi_score_tokens": (C.c_int, [_P, _P, _I32P, _I32P, C.c_int, C.c_int, C.POINTER(SampleParams), _F32P, _I32P, _F32P]),
     "mi_step_enqueue": (C.c_int, [_P, _P, _I32P, C.c_int, C.c_int, C.POINTER(SampleParams), C.POINTER(C.c_int64)]),
     "mi_step_wait": (C.c_int, [_P, C.c_int64, _I32P, _F32P, _F32P, _I32P, _F32P]),
     "mi_profile_select": (C.c_int, [_P, C.c_char_p]),

@@ -80,6 +80,7 @@ struct mi_engine {
   void* h = nullptr; void* qkv = nullptr; void* q = nullptr; void* attn = nullptr; void* act = nullptr;
   float* logits = nullptr; float* lora_t = nullptr;
   int32_t* d_tokens = nullptr; size_t d_tokens_cap = 0;
+  int32_t* d_forced = nullptr; size_t d_forced_cap = 0;   // mi_score_tokens targets
   int32_t* d_next = nullptr;      // tokens sampled by the last step [maxB]
   float* d_logprob = nullptr; float* d_prob0 = nullptr; float* d_rowstats = nullptr; float* d_uniforms = nullptr;
   int32_t* d_topk_ids = nullptr; float* d_topk_lp = nullptr;
@@ -439,7 +440,7 @@ int upload_tokens(mi_engine* e, const int32_t* tokens, int B, int L) {
   return MI_OK;
 }
 
-int run_sample(mi_engine* e, int B, const mi_sample_params* sp) {
+int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* forced = nullptr) {
   mi_sample_params def{}; def.temperature = 0.f; def.top_p = 1.f;
   if (!sp) sp = &def;
   hipStream_t st = e->stream;
@@ -449,15 +450,17 @@ int run_sample(mi_engine* e, int B, const mi_sample_params* sp) {
     MI_HIP(hipMemcpyAsync(e->d_bias_ids, sp->logit_bias_ids, sp->n_logit_bias * sizeof(int32_t), hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(e->d_bias_vals, sp->logit_bias_values, sp->n_logit_bias * sizeof(float), hipMemcpyHostToDevice, st));
   }
-  if (sp->uniforms) MI_HIP(hipMemcpyAsync(e->d_uniforms, sp->uniforms, B * sizeof(float), hipMemcpyHostToDevice, st));
+  if (sp->uniforms && !forced) MI_HIP(hipMemcpyAsync(e->d_uniforms, sp->uniforms, B * sizeof(float), hipMemcpyHostToDevice, st));
   Prof pr(e, "sample");
   SampleCall sc{};
   sc.logits = e->logits; sc.B = B; sc.V = e->d.vocab_size; sc.rnd = RND_NONE;
   sc.temperature = sp->temperature; sc.top_p = sp->top_p;
   sc.n_bias = sp->n_logit_bias; sc.bias_ids = e->d_bias_ids; sc.bias_vals = e->d_bias_vals;
-  sc.uniforms = sp->uniforms ? e->d_uniforms : nullptr; sc.seed = sp->seed; sc.step = e->step_counter++;
+  sc.forced = forced;
+  sc.uniforms = (sp->uniforms && !forced) ? e->d_uniforms : nullptr; sc.seed = sp->seed; sc.step = e->step_counter++;
   sc.top_logprobs = sp->top_logprobs;
-  sc.tokens_out = e->d_next; sc.logprob_out = e->d_logprob; sc.prob_row0_out = e->d_prob0;
+  sc.lp_temp = sp->logprobs_at_temperature;
+  sc.tokens_out = e->d_next; sc.logprob_out = e->d_logprob; sc.prob_row0_out = forced ? nullptr : e->d_prob0;
   sc.topk_ids = e->d_topk_ids; sc.topk_logprobs = e->d_topk_lp; sc.row_stats = e->d_rowstats;
   return launch_sample(sc, st);
 }
@@ -516,7 +519,7 @@ void mi_engine_destroy(mi_engine* e) {
   hipFree(e->final_norm32); hipFree(e->xn);
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
-  hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t);
+  hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {
@@ -736,6 +739,35 @@ int mi_forward(mi_engine* e, mi_kv* kv, const int32_t* tokens, int B, int L, flo
     MI_HIP(hipMemcpyAsync(logits_out, e->logits, (all_pos ? R : (size_t)B) * e->d.vocab_size * sizeof(float),
                           hipMemcpyDeviceToHost, e->stream));
   MI_HIP(hipStreamSynchronize(e->stream));
+  return MI_OK;
+}
+
+int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_t* targets, int B, int L,
+                    const mi_sample_params* sp, float* logprob_out, int32_t* topk_ids, float* topk_logprobs) {
+  MI_TRY(check_call(e, kv, B, L));
+  if (!tokens || !targets || !logprob_out) return fail(MI_ERR_INVALID, "null argument");
+  const size_t R = (size_t)B * L;
+  if (R > (size_t)(1 << 20)) return fail(MI_ERR_INVALID, "score: too many positions in one call");
+  const int k = sp ? sp->top_logprobs : 0;
+  if (k > 0 && (!topk_ids || !topk_logprobs)) return fail(MI_ERR_INVALID, "score: top_logprobs > 0 needs output buffers");
+  MI_TRY(ensure_workspace(e, R, R, (int)R));
+  hipStream_t st = e->stream;
+  if (R > e->d_forced_cap) {
+    MI_HIP(hipStreamSynchronize(st));
+    hipFree(e->d_forced);
+    MI_HIP(hipMalloc(&e->d_forced, R * sizeof(int32_t)));
+    e->d_forced_cap = R;
+  }
+  MI_TRY(upload_tokens(e, tokens, B, L));
+  MI_HIP(hipMemcpyAsync(e->d_forced, targets, R * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  MI_TRY(forward_device(e, kv, B, L, true, true));
+  MI_TRY(run_sample(e, (int)R, sp, e->d_forced));
+  MI_HIP(hipMemcpyAsync(logprob_out, e->d_logprob, R * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (k > 0) {
+    MI_HIP(hipMemcpyAsync(topk_ids, e->d_topk_ids, R * k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(topk_logprobs, e->d_topk_lp, R * k * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  MI_HIP(hipStreamSynchronize(st));
   return MI_OK;
 }
 

@@ -158,6 +158,8 @@ struct SampleCall {
   const float* uniforms;     // device [B] or null
   uint64_t seed, step;       // Philox key/counter when uniforms == null
   int top_logprobs;
+  int lp_temp;               // report logprobs under softmax(logits / temperature) (temperature > 0)
+  const int32_t* forced;     // device [B] or null: teacher forcing -- score these ids instead of sampling (< 0: skip row)
   int32_t* tokens_out;       // device [B]
   float* logprob_out;        // device [B]
   float* prob_row0_out;      // device [B]

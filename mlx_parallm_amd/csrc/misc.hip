@@ -260,7 +260,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   if (threadIdx.x == 0 && c.row_stats) { c.row_stats[2 * b] = mx; c.row_stats[2 * b + 1] = lse; }
 
   int token = a.i;
-  if (c.temperature != 0.f) {
+  const int forced = c.forced ? c.forced[b] : 0;
+  if (c.forced) {
+    if (forced >= 0 && forced < V) token = forced;
+  } else if (c.temperature != 0.f) {
     const float inv_t = 1.0f / c.temperature;
     // total mass Z (integer): target = +inf prefix
     Prefix all = find_prefix(lg, V, mx, inv_t, ~0ull, hist_m, hist_c, &sh_p);
@@ -291,9 +294,18 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
     token = nth_tie(lg, V, key, rank_in_key, sh_i);
     if (token < 0 || token >= V) token = a.i;
   }
+  // logprobs are reported as (lg - mx) * lp_scale - lp_lse: the plain log-softmax, or the one of logits / T
+  float lp_scale = 1.0f, lp_lse = lse - mx;
+  if (c.lp_temp && c.temperature > 0.f) {
+    lp_scale = 1.0f / c.temperature;
+    float st = 0.f;
+    for (int i = threadIdx.x; i < V; i += ST) st += __expf((lg[i] - mx) * lp_scale);
+    st = block_sum(st, sh_f);
+    lp_lse = __logf(st);
+  }
   if (threadIdx.x == 0) {
     c.tokens_out[b] = token;
-    if (c.logprob_out) c.logprob_out[b] = lg[token] - lse;
+    if (c.logprob_out) c.logprob_out[b] = (c.forced && forced < 0) ? 0.f : (lg[token] - mx) * lp_scale - lp_lse;
   }
   // ---- top-k logprobs: k rounds of arg-max with exclusion of already emitted ids
   if (c.top_logprobs > 0) {
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
       t = block_argmax(t, sh_am);
       if (threadIdx.x == 0) {
         c.topk_ids[(size_t)b * c.top_logprobs + r] = t.i;
-        c.topk_logprobs[(size_t)b * c.top_logprobs + r] = t.v - lse;
+        c.topk_logprobs[(size_t)b * c.top_logprobs + r] = (t.v - mx) * lp_scale - lp_lse;
       }
       prev_v = t.v; prev_i = t.i;
     }

@@ -161,7 +161,7 @@ int mi_op_sample(float* logits, int B, int V, float temperature, float top_p, co
   MI_TRY(ready());
   SampleCall sc{};
   sc.logits = logits; sc.B = B; sc.V = V; sc.rnd = RND_NONE; sc.temperature = temperature; sc.top_p = top_p;
-  sc.uniforms = uniforms; sc.seed = 0; sc.step = 0; sc.top_logprobs = top_logprobs;
+  sc.uniforms = uniforms; sc.seed = 0; sc.step = 0; sc.top_logprobs = top_logprobs; sc.lp_temp = 0;
   sc.tokens_out = tokens_out; sc.logprob_out = logprob_out; sc.prob_row0_out = prob_row0_out;
   sc.topk_ids = topk_ids; sc.topk_logprobs = topk_logprobs; sc.row_stats = row_stats;
   MI_TRY(launch_sample(sc, nullptr));

@@ -49,12 +49,14 @@ class SampleArgs:
     """Arguments of the reference's ``sample`` closure (utils.py:345-364)."""
 
     def __init__(self, temp: float = 0.0, top_p: float = 1.0, logit_bias: Optional[Dict[int, float]] = None,
-                 uniforms: Optional[Sequence[float]] = None, seed: int = 0, top_logprobs: int = 0):
+                 uniforms: Optional[Sequence[float]] = None, seed: int = 0, top_logprobs: int = 0,
+                 logprobs_at_temperature: bool = False):
         self.c = L.SampleParams()
         self.c.temperature = float(temp)
         self.c.top_p = float(top_p)
         self.c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.c.top_logprobs = int(top_logprobs)
+        self.c.logprobs_at_temperature = 1 if logprobs_at_temperature else 0
         self._keep = []
         if logit_bias:
             ids = np.ascontiguousarray(list(logit_bias.keys()), dtype=np.int32)
@@ -277,6 +279,29 @@ class Engine:
         res = {"tokens": toks, "logprobs": lp, "probs_row0": p0}
         if k > 0:
             res["top_ids"], res["top_logprobs"] = tk_i[:, :k], tk_l[:, :k]
+        return res
+
+    def score_tokens(self, kv: KVCache, tokens, targets, sample: Optional[SampleArgs] = None):
+        """Teacher-forced scoring (``mi_score_tokens``): tokens / targets (B, L) -> dict ``logprobs (B, L)``
+        [+ ``top_ids`` / ``top_logprobs`` (B, L, k)]; the tokens are appended to ``kv``."""
+        sp = sample or SampleArgs()
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        tgt = np.ascontiguousarray(targets, dtype=np.int32)
+        if tok.ndim != 2 or tok.shape != tgt.shape:
+            raise ValueError("score_tokens: tokens and targets must both be (B, L)")
+        B, Lt = tok.shape
+        kv.ensure(max(kv.offsets) + Lt)
+        k = int(sp.c.top_logprobs)
+        lp = np.empty((B, Lt), dtype=np.float32)
+        ti = np.empty((B, Lt, max(k, 1)), dtype=np.int32)
+        tl = np.empty((B, Lt, max(k, 1)), dtype=np.float32)
+        L.check(L.lib().mi_score_tokens(self._h, kv._h, tok.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        tgt.ctypes.data_as(C.POINTER(C.c_int32)), B, Lt, C.byref(sp.c),
+                                        lp.ctypes.data_as(C.POINTER(C.c_float)),
+                                        ti.ctypes.data_as(C.POINTER(C.c_int32)), tl.ctypes.data_as(C.POINTER(C.c_float))))
+        res = {"logprobs": lp}
+        if k > 0:
+            res["top_ids"], res["top_logprobs"] = ti[:, :, :k], tl[:, :, :k]
         return res
 
     def decode_sample(self, kv: KVCache, tokens, sample: Optional[SampleArgs] = None):

@@ -173,6 +173,7 @@ def generate_step(
     uniforms_fn: Optional[Callable[[int], np.ndarray]] = None,
     top_logprobs: int = 0,
     return_details: bool = False,
+    logprobs_at_temperature: bool = False,
 ) -> Generator[Tuple[np.ndarray, np.ndarray], None, None]:
     """A generator producing token ids from the given prompts (utils.py:315-427).
 
@@ -183,7 +184,9 @@ def generate_step(
     (utils.py:420-427) step n+1 is launched before step n's tokens are read back.
 
     Extensions (keyword only): ``seed`` (Philox key for temp > 0), ``uniforms_fn(step) -> (B,)``
-    caller-supplied noise, ``top_logprobs``, ``return_details`` (yield a dict instead).
+    caller-supplied noise, ``top_logprobs``, ``return_details`` (yield the dict ``tokens / logprobs /
+    probs_row0 / top_ids / top_logprobs`` instead), ``logprobs_at_temperature`` (report logprobs under
+    ``softmax(logits / temp)``, as the server's logprobs path does, instead of ``softmax(logits)``).
     """
     if repetition_penalty:
         raise NotImplementedError("repetition_penalty not supported.")           # utils.py:366-367
@@ -201,7 +204,7 @@ def generate_step(
     def args_for(step: int) -> SampleArgs:
         u = uniforms_fn(step) if (uniforms_fn is not None and temp != 0) else None
         return SampleArgs(temp=temp, top_p=top_p, logit_bias=logit_bias, uniforms=u, seed=seed,
-                          top_logprobs=top_logprobs)
+                          top_logprobs=top_logprobs, logprobs_at_temperature=logprobs_at_temperature)
 
     def emit(res):
         if return_details:
@@ -468,8 +471,8 @@ def batch_stream_generate_text(model, tokenizer, prompts_tokens, max_tokens: int
 # --------- server async batch API (utils.py:1087-1346) ---------
 async def batch_generate_text(model, tokenizer, prompts: List[str], max_tokens: int = 100, temp: float = 0.7,
                               top_p: float = 1.0, disable_prefix_cache: bool = False,
-                              max_context_length: Optional[int] = None, *, seed: int = 0
-                              ) -> List[Tuple[str, int, int]]:
+                              max_context_length: Optional[int] = None, *, seed: int = 0,
+                              stats: Optional[Dict[str, float]] = None) -> List[Tuple[str, int, int]]:
     """-> [(text, n_prompt_tokens, n_completion_tokens)] per prompt (utils.py:1087-1346).
 
     Tokenise (left pad, truncate to the effective max length), optional shared-prefix prefill,
@@ -477,7 +480,8 @@ async def batch_generate_text(model, tokenizer, prompts: List[str], max_tokens: 
     defects recorded in SURVEY App. C: the common prefix is only split off when it is actually
     prefilled (D2), at least one real token is always left in the suffix, and the process-global
     prefix-KV cache (D1) is not carried over.  Runs in the default executor like the reference
-    (utils.py:1345)."""
+    (utils.py:1345).  ``stats`` (keyword only, optional) receives ``prompt_tokens / prompt_time /
+    decode_tokens / decode_time`` for the server's ``/debug/metrics`` tokens-per-second keys."""
     if not prompts:
         return []
     loop = asyncio.get_running_loop()
@@ -536,10 +540,12 @@ async def batch_generate_text(model, tokenizer, prompts: List[str], max_tokens: 
         generated: List[List[int]] = [[] for _ in range(B)]
         active = [True] * B
         counts = [0] * B
-        for step_num, (ids, _) in enumerate(
-                generate_step(suffix_batch, model, cache=caches, temp=temp, top_p=top_p, seed=seed)):
-            if step_num >= max_tokens:
-                break
+        t_start = time.perf_counter()
+        t_first = None
+        for step_num, (ids, _) in _take(
+                generate_step(suffix_batch, model, cache=caches, temp=temp, top_p=top_p, seed=seed), max_tokens):
+            if t_first is None:
+                t_first = time.perf_counter()
             any_active = False
             for i in range(B):
                 if not active[i]:
@@ -553,6 +559,11 @@ async def batch_generate_text(model, tokenizer, prompts: List[str], max_tokens: 
                     counts[i] += 1
             if not any_active:
                 break
+        if stats is not None:
+            t_end = time.perf_counter()
+            t_first = t_first if t_first is not None else t_end
+            stats.update(prompt_tokens=float(sum(n_prompt)), prompt_time=t_first - t_start,
+                         decode_tokens=float(sum(len(g) for g in generated)), decode_time=t_end - t_first)
         return [(tokenizer.decode(generated[i], skip_special_tokens=True), n_prompt[i], len(generated[i]))
                 for i in range(B)]
 

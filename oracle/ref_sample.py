@@ -57,7 +57,7 @@ def inverse_cdf_pick(ids: np.ndarray, probs: np.ndarray, u: float) -> int:
 
 def sample(logits: np.ndarray, temp: float = 0.0, top_p: float = 1.0,
            logit_bias: Optional[Dict[int, float]] = None,
-           uniforms: Optional[np.ndarray] = None):
+           uniforms: Optional[np.ndarray] = None, logprobs_at_temperature: bool = False):
     """utils.py:345-364.  logits (B, V) float32.  Returns dict with
     tokens (B,1) int64, probs (B,1) = softmax(logits)[0, tokens] (row-0 quirk Q6),
     logprobs (B,) = log_softmax(logits)[b, token_b]."""
@@ -87,5 +87,8 @@ def sample(logits: np.ndarray, temp: float = 0.0, top_p: float = 1.0,
             tokens[b] = inverse_cdf_pick(ids, pr, float(uniforms[b]))
     tokens = tokens.reshape(B, 1)
     probs = np.exp(lsm[0, tokens[:, 0]]).reshape(B, 1).astype(np.float32)   # utils.py:363 (Q6)
-    logprobs = lsm[np.arange(B), tokens[:, 0]].astype(np.float32)
-    return {"tokens": tokens, "probs": probs, "logprobs": logprobs, "log_softmax": lsm}
+    lsm_out = lsm
+    if logprobs_at_temperature and temp > 0:       # server/main.py:571-584: softmax(logits * (1 / T))
+        lsm_out = log_softmax(logits * np.float32(1.0 / temp))
+    logprobs = lsm_out[np.arange(B), tokens[:, 0]].astype(np.float32)
+    return {"tokens": tokens, "probs": probs, "logprobs": logprobs, "log_softmax": lsm_out}

@@ -64,13 +64,41 @@ class FakeEngine:
         u = getattr(sample, "_u", None) if c.uniforms else None
         if c.temperature != 0 and u is None:
             u = np.random.default_rng(int(c.seed) + self._next).random(tokens.shape[0])
-        s = ref_sample.sample(logits, temp=float(c.temperature), top_p=float(c.top_p), logit_bias=bias, uniforms=u)
+        s = ref_sample.sample(logits, temp=float(c.temperature), top_p=float(c.top_p), logit_bias=bias, uniforms=u,
+                              logprobs_at_temperature=bool(c.logprobs_at_temperature))
         self._last_tokens = s["tokens"]
         t = self._next
         self._next += 1
-        self._results[t] = {"tokens": s["tokens"][:, 0].astype(np.int32), "logprobs": s["logprobs"],
-                            "probs_row0": s["probs"][:, 0]}
+        res = {"tokens": s["tokens"][:, 0].astype(np.int32), "logprobs": s["logprobs"], "probs_row0": s["probs"][:, 0]}
+        k = int(c.top_logprobs)
+        if k > 0:   # (value desc, id asc), like the device sampler
+            lsm = s["log_softmax"]
+            order = np.stack([np.lexsort((np.arange(lsm.shape[1]), -lsm[b]))[:k] for b in range(lsm.shape[0])])
+            res["top_ids"] = order.astype(np.int32)
+            res["top_logprobs"] = np.take_along_axis(lsm, order, axis=1).astype(np.float32)
+        self._results[t] = res
         return t
+
+    def score_tokens(self, kv, tokens, targets, sample=None):
+        tokens, targets = np.asarray(tokens), np.asarray(targets)
+        lg = np.array(self.ref(tokens, cache=kv.caches), dtype=np.float32)
+        self.trace.append(("score", tokens.shape))
+        c = sample.c
+        for i in range(c.n_logit_bias):
+            lg[:, :, int(c.logit_bias_ids[i])] += np.float32(c.logit_bias_values[i])
+        if c.logprobs_at_temperature and c.temperature > 0:
+            lg = lg * np.float32(1.0 / c.temperature)
+        B, Lt, V = lg.shape
+        lsm = ref_sample.log_softmax(lg.reshape(B * Lt, V)).reshape(B, Lt, V)
+        tg = np.clip(targets, 0, V - 1)
+        lp = np.take_along_axis(lsm, tg[..., None], axis=2)[..., 0]
+        res = {"logprobs": np.where(targets < 0, 0.0, lp).astype(np.float32)}
+        k = int(c.top_logprobs)
+        if k > 0:
+            order = np.stack([np.lexsort((np.arange(V), -row))[:k] for row in lsm.reshape(B * Lt, V)]).reshape(B, Lt, k)
+            res["top_ids"] = order.astype(np.int32)
+            res["top_logprobs"] = np.take_along_axis(lsm, order, axis=2).astype(np.float32)
+        return res
 
     def step_wait(self, ticket, batch_size, top_logprobs=0):
         self.trace.append(("wait", ticket))
@@ -89,6 +117,15 @@ class FakeModel:
         self.layers = [_Layer() for _ in range(cfg.num_hidden_layers)]
         self.head_dim = cfg.head_dim
         self.n_kv_heads = cfg.num_key_value_heads
+
+    def __call__(self, inputs, cache=None, last_only=False):
+        tokens = np.asarray(inputs)
+        if tokens.ndim == 1:
+            tokens = tokens[None]
+        caches = self.ref.make_cache(tokens.shape[0], paged=False) if cache is None else \
+            self.bind_cache(cache, tokens.shape[0], tokens.shape[1]).caches
+        lg = self.ref(tokens, cache=caches).astype(np.float32)
+        return lg[:, -1:, :] if last_only else lg
 
     def bind_cache(self, cache, batch, new_tokens):
         g = group_of(cache)

@@ -236,6 +236,55 @@ def test_top_p_sampling_with_logprobs_matches_oracle(tiny_dirs):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_f32", "llama_bf16_gqa"])
+def test_score_tokens_and_temperature_logprobs_match_oracle(tiny_dirs, name):
+    """mi_score_tokens (teacher-forced log-softmax gather + top-k over all positions, through the KV
+    cache in two chunks) and logprobs_at_temperature of the sampler."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    tol = 2e-4 if name == "llama_f32" else 3e-2
+    B, Lt, V = 2, 12, cfg["vocab_size"]
+    toks = RNG.integers(0, V, size=(B, Lt + 1))
+    lg = np.asarray(ref(toks[:, :-1], cache=ref.make_cache(B, paged=False)), dtype=np.float32)      # (B, Lt, V)
+    tg = toks[:, 1:].copy()
+    tg[1, 3] = -1                                                  # skipped position
+    for temp, bias in ((0.0, None), (0.5, {7: 1.5, 11: -2.0})):
+        l2 = lg.copy()
+        for k, v in (bias or {}).items():
+            l2[:, :, k] += np.float32(v)
+        if temp > 0:
+            l2 = l2 * np.float32(1.0 / temp)
+        lsm = ref_sample.log_softmax(l2.reshape(B * Lt, V)).reshape(B, Lt, V)
+        kv = model.engine.new_kv(B, capacity=32, kv_dtype="model")
+        sp = SampleArgs(temp=temp, logit_bias=bias, top_logprobs=3, logprobs_at_temperature=True)
+        a = model.engine.score_tokens(kv, toks[:, :5], tg[:, :5], sp)
+        b = model.engine.score_tokens(kv, toks[:, 5:Lt], tg[:, 5:], sp)
+        assert kv.offsets == [Lt, Lt]
+        got = np.concatenate([a["logprobs"], b["logprobs"]], axis=1)
+        want = np.take_along_axis(lsm, np.clip(tg, 0, V - 1)[..., None], axis=2)[..., 0]
+        want[1, 3] = 0.0
+        assert np.abs(got - want).max() <= tol * max(1.0, 1.0 / max(temp, 1e-9) if temp else 1.0)
+        top_l = np.concatenate([a["top_logprobs"], b["top_logprobs"]], axis=1)
+        assert np.abs(top_l - np.sort(lsm, axis=2)[:, :, ::-1][:, :, :3]).max() <= tol * (2 if temp else 1)
+        if name == "llama_f32":
+            top_i = np.concatenate([a["top_ids"], b["top_ids"]], axis=1)
+            assert np.array_equal(top_i[0, 0], np.lexsort((np.arange(V), -lsm[0, 0]))[:3])
+        kv.close()
+    # sampler: logprob of the sampled token under softmax(logits / T)
+    us = RNG.random((4, B)).astype(np.float32)
+    gen = utils.generate_step(toks[:, :6], model, temp=0.7, top_p=0.9, uniforms_fn=lambda s: us[s],
+                              cache=model.make_cache(B, paged=False), return_details=True, top_logprobs=2,
+                              logprobs_at_temperature=True)
+    want = ref_generate.generate_step(toks[:, :6], ref, temp=0.7, top_p=0.9, uniforms_fn=lambda s: us[s], paged=False,
+                                      return_logits=True)
+    for (g, (wt, _wp, wl, _wlp)), _ in zip(zip(gen, want), range(2)):
+        lsm_t = ref_sample.log_softmax(np.asarray(wl, dtype=np.float32) * np.float32(1.0 / 0.7))
+        if name == "llama_f32":
+            assert np.array_equal(g["tokens"], wt[:, 0])
+            assert np.allclose(g["logprobs"], lsm_t[np.arange(B), wt[:, 0]], atol=1e-3)
+        assert np.allclose(g["top_logprobs"], np.sort(lsm_t, axis=1)[:, ::-1][:, :2], atol=tol * 2)
+    model.engine.close()
+
+
 def test_kv_growth_keeps_contents_and_reset(tiny_dirs):
     model, ref, cfg = _load_pair(tiny_dirs, "llama_f32", max_pos=1024)
     toks = _left_pad_prompts(cfg, 2, 6, ragged=False)
