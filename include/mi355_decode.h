@@ -163,7 +163,13 @@ int mi_step_wait(mi_engine* e, int64_t ticket, int32_t* tokens_out, float* logpr
 int mi_profile_select(mi_engine* e, const char* name);
 /* Drains the recorded events: number of launches and their summed duration in ms. */
 int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
-/* Enable/disable hipGraph replay of the decode step (default on). */
+/* Engine switches (A/B measurement and tests); unknown key -> MI_ERR_NOTFOUND.
+ *   "force_generic_gemv"      1: every linear layer on the generic VALU kernel (default 0)
+ *   "fused_decode_attention"  0: decode attention as rope/append + attention + combine launches (default 1)
+ *   "prefill_gemm"            0: prefill through the chunked <= 16-row kernels instead of the tile GEMM (default 1)
+ *   "fused_gemv_pairs"        bit 0: o_proj -> gate|up, bit 1: down_proj -> next layer's q|k|v as ONE launch
+ *                             each with an in-launch seam (default 0: measured no faster than two launches)
+ *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1) */
 int mi_engine_set_option(mi_engine* e, const char* key, int64_t value);
 /* Blocks until the engine's stream is idle. */
 int mi_engine_sync(mi_engine* e);

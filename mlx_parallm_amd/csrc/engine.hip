@@ -97,6 +97,12 @@ struct mi_engine {
   int opt_fused_attn = 1;
   int opt_tile_weights = 1;
   int opt_prefill_gemm = 1;
+  int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
+                                         // Off: measured on Mistral-7B bf16 B=8 the in-launch seam costs what the kernel
+                                         // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
+  unsigned* d_seam_counter = nullptr;    // arrival counter of the in-launch seams (monotonic)
+  int* d_seam_error = nullptr;           // set by a workgroup that gave up waiting at a seam
+  unsigned seam_base = 0;                // value of *d_seam_counter once every enqueued launch has run
   void* xn = nullptr;            // [rows][max(H, I)] normalised activations of the prefill GEMMs
 };
 
@@ -318,6 +324,39 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   return MI_OK;
 }
 
+// decode: two dependent GEMVs (b reads a's output) in one launch when the MFMA pair kernel supports them
+bool can_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear& fb, GemvCall b, size_t rows) {
+  if (!e->opt_fused_pairs || rows > 8) return false;
+  a.force_v1 = b.force_v1 = e->opt_force_v1;
+  a.M = b.M = (int)rows;
+  if (fa.W.lora_b[0] || fa.W.lora_b[1] || fb.W.lora_b[0] || fb.W.lora_b[1]) return false;
+  return gemv_pair_supported(fa.W, a, fb.W, b);
+}
+
+int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear& fb, GemvCall b, size_t rows,
+              const char* prof) {
+  a.M = b.M = (int)rows;
+  if (e->d_seam_counter == nullptr) {
+    MI_HIP(hipMalloc(&e->d_seam_counter, sizeof(unsigned)));
+    MI_HIP(hipMalloc(&e->d_seam_error, sizeof(int)));
+    MI_HIP(hipMemsetAsync(e->d_seam_counter, 0, sizeof(unsigned), e->stream));
+    MI_HIP(hipMemsetAsync(e->d_seam_error, 0, sizeof(int), e->stream));
+    e->seam_base = 0;
+  }
+  const bool selected = !e->prof_name.empty() && e->prof_name == prof;
+  Prof pr(e, selected ? "" : prof);
+  if (selected) {
+    hipEvent_t x = nullptr, y = nullptr;
+    hipEventCreate(&x); hipEventCreate(&y);
+    a.ev_start = x; a.ev_stop = y;
+    e->prof_events.emplace_back(x, y);
+  }
+  GemvSeam s{e->d_seam_counter, e->seam_base, e->d_seam_error};
+  MI_TRY(launch_gemv_pair(fa.W, a, fb.W, b, s, e->stream));
+  e->seam_base += (unsigned)gemv_pair_grid();
+  return MI_OK;
+}
+
 int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L) {
   if (L != 1) return 1;
   int mx = 0;
@@ -362,6 +401,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     (void)need;
   }
 
+  bool qkv_done = false;     // this layer's q|k|v already ran behind the previous layer's down_proj
   for (int li = 0; li < d.num_layers; ++li) {
     LayerW& lw = e->layers[li];
     const bool w32 = quirk && d.act_dtype != MI_F32;     // norm weights must match the activation storage type
@@ -371,11 +411,16 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     const void* k_norm = w32 ? lw.k_norm32 : lw.k_norm;
     // everything up to the layer-0 attention still rounds to the model dtype in quirk mode
     const int rnd = (quirk && li == 0) ? rndT : RND_NONE;
-    {  // input_layernorm + q|k|v projections (llama.py:187,93)
-      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = rnd; c.pro = PRO_NORM; c.norm_w = in_norm;
+    auto qkv_call = [&](int layer) {  // input_layernorm + q|k|v projections (llama.py:187,93)
+      const LayerW& l2 = e->layers[layer];
+      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = (quirk && layer == 0) ? rndT : RND_NONE; c.pro = PRO_NORM;
+      c.norm_w = w32 ? l2.in_norm32 : l2.in_norm;
       c.eps = d.rms_norm_eps; c.epi = EPI_STORE; c.out = e->qkv; c.ldo = nqkv;
-      MI_TRY(gemv_rows(e, lw.qkv, c, R, es, es, "gemv_qkv"));
-    }
+      return c;
+    };
+    (void)in_norm;
+    if (!qkv_done) MI_TRY(gemv_rows(e, lw.qkv, qkv_call(li), R, es, es, "gemv_qkv"));
+    qkv_done = false;
     AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap};
     void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
@@ -395,19 +440,29 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
         AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial};
         MI_TRY(launch_attention(ac, st)); }
     }
-    {  // o_proj + residual (llama.py:143,188)
-      GemvCall c; c.x = e->attn; c.ldx = Hq * D; c.act = act; c.rnd = RND_NONE; c.epi = EPI_RESID;
-      c.resid = e->h; c.ldo = H;
-      MI_TRY(gemv_rows(e, lw.o, c, R, es, es, "gemv_o"));
+    {
+      // o_proj + residual (llama.py:143,188)
+      GemvCall co; co.x = e->attn; co.ldx = Hq * D; co.act = act; co.rnd = RND_NONE; co.epi = EPI_RESID;
+      co.resid = e->h; co.ldo = H;
+      // post_attention_layernorm + gate|up + SwiGLU (llama.py:189,165)
+      GemvCall cg; cg.x = e->h; cg.ldx = H; cg.act = act; cg.rnd = RND_NONE; cg.pro = PRO_NORM; cg.norm_w = post_norm;
+      cg.eps = d.rms_norm_eps; cg.epi = EPI_SWIGLU; cg.out = e->act; cg.ldo = I; cg.pair_offset = I;
+      if ((e->opt_fused_pairs & 1) && can_pair(e, lw.o, co, lw.gate_up, cg, R)) {
+        MI_TRY(gemv_pair(e, lw.o, co, lw.gate_up, cg, R, "gemv_o_gate_up"));
+      } else {
+        MI_TRY(gemv_rows(e, lw.o, co, R, es, es, "gemv_o"));
+        MI_TRY(gemv_rows(e, lw.gate_up, cg, R, es, es, "gemv_gate_up"));
+      }
     }
-    {  // post_attention_layernorm + gate|up + SwiGLU (llama.py:189,165)
-      GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = post_norm;
-      c.eps = d.rms_norm_eps; c.epi = EPI_SWIGLU; c.out = e->act; c.ldo = I; c.pair_offset = I;
-      MI_TRY(gemv_rows(e, lw.gate_up, c, R, es, es, "gemv_gate_up"));
-    }
-    {  // down_proj + residual (llama.py:165,190)
+    {  // down_proj + residual (llama.py:165,190); with the next layer's q|k|v behind it in the same launch
       GemvCall c; c.x = e->act; c.ldx = I; c.act = act; c.rnd = RND_NONE; c.epi = EPI_RESID; c.resid = e->h; c.ldo = H;
-      MI_TRY(gemv_rows(e, lw.down, c, R, es, es, "gemv_down"));
+      if ((e->opt_fused_pairs & 2) && li + 1 < d.num_layers &&
+          can_pair(e, lw.down, c, e->layers[li + 1].qkv, qkv_call(li + 1), R)) {
+        MI_TRY(gemv_pair(e, lw.down, c, e->layers[li + 1].qkv, qkv_call(li + 1), R, "gemv_down_qkv"));
+        qkv_done = true;
+      } else {
+        MI_TRY(gemv_rows(e, lw.down, c, R, es, es, "gemv_down"));
+      }
     }
   }
   if (want_logits) {  // final norm + lm_head / tied embedding (llama.py:231,249-252)
@@ -520,6 +575,7 @@ void mi_engine_destroy(mi_engine* e) {
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
+  hipFree(e->d_seam_counter); hipFree(e->d_seam_error);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {
@@ -854,6 +910,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
   if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
   if (k == "prefill_gemm") { e->opt_prefill_gemm = value != 0; return MI_OK; }
+  if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "tile_weights") {
     if (e->finalized) return fail(MI_ERR_INVALID, "tile_weights must be set before mi_engine_finalize");
     e->opt_tile_weights = value != 0; return MI_OK;

@@ -52,6 +52,19 @@ struct GemvCall {
 
 int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
 
+// Two dependent decode GEMVs as ONE launch (gemv_mfma.hip, gemv_pair_kernel): B reads what A wrote.
+// `counter` is a device word that every launch advances by gemv_pair_grid(); `base` is its value before
+// this launch (the host keeps the running total); `error` is set to 1 if a workgroup gave up waiting.
+struct GemvSeam {
+  unsigned* counter;
+  unsigned base;
+  int* error;
+};
+bool gemv_pair_supported(const LinearW& WA, const GemvCall& a, const LinearW& WB, const GemvCall& b);
+int launch_gemv_pair(const LinearW& WA, const GemvCall& a, const LinearW& WB, const GemvCall& b, const GemvSeam& s,
+                     hipStream_t st);
+int gemv_pair_grid();
+
 // prefill (many rows): MFMA tile GEMM + row-wise RMSNorm (gemm_prefill.hip)
 bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows);
 int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st);

@@ -163,6 +163,29 @@ def test_fused_and_unfused_decode_attention_agree(tiny_dirs, name):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
+def test_paired_gemv_launches_are_bit_identical(tiny_dirs, name):
+    """fused_gemv_pairs (o_proj -> gate|up and down_proj -> next q|k|v as one launch each, in-launch seam with
+    write-through hand-off) must give exactly the logits of the one-launch-per-GEMV path."""
+    model, _ref, cfg = _load_pair(tiny_dirs, name)
+    B = 3
+    toks = _left_pad_prompts(cfg, B, 9, ragged=False)
+    outs = []
+    for opt in (0, 3):
+        model.engine.set_option("fused_gemv_pairs", opt)
+        kv = model.engine.new_kv(B, capacity=64, kv_dtype="model")
+        model.engine.forward(toks, kv, want_logits=False)
+        y, steps = toks[:, -1:], []
+        for _ in range(6):
+            lg = model.engine.forward(y, kv)
+            steps.append(lg)
+            y = np.argmax(lg, axis=-1)[:, None].astype(np.int32)
+        outs.append(np.stack(steps))
+        kv.close()
+    assert np.array_equal(outs[0], outs[1])
+    model.engine.close()
+
+
 @pytest.mark.parametrize("name", ["llama_bf16_gqa", "qwen3_bf16"])
 def test_prefill_tile_gemm_matches_oracle_and_chunked_path(tiny_dirs, name):
     """Prefill with enough rows (B*L = 172, not a multiple of the 128-row tile) to take the MFMA tile
