@@ -95,11 +95,12 @@ int mi_op_rope_append(const mi_op_attn_shape* s, const void* qkv, void* q_out, v
 int mi_op_attention(const mi_op_attn_shape* s, const void* q, const void* kcache, const void* vcache,
                     const int32_t* offsets, void* out, float scale, int nsplit, float* partial);
 /* fused decode attention (L == 1): q/k norm + RoPE + append + split-KV attention + combine.
- * counters: [B*Hkv] zero-initialised ints.  iters > 1 repeats the launch (timing; avg_ms may be NULL). */
+ * counters: [B*Hkv] zero-initialised ints.  variant 0: MFMA kernel where it applies (16-bit caches,
+ * head_dim % 32 == 0), 1: VALU kernel.  iters > 1 repeats the launch (timing; avg_ms may be NULL). */
 int mi_op_attention_decode(const mi_op_attn_shape* s, const void* qkv, void* kcache, void* vcache,
                            const int32_t* offsets, const void* q_norm_w, const void* k_norm_w, float eps,
                            const float* cos_tab, const float* sin_tab, void* out, float scale, int rnd_out,
-                           int nsplit, float* partial, int32_t* counters, int iters, float* avg_ms);
+                           int nsplit, float* partial, int32_t* counters, int variant, int iters, float* avg_ms);
 int mi_op_sample(float* logits, int B, int V, float temperature, float top_p, const float* uniforms,
                  int top_logprobs, int32_t* tokens_out, float* logprob_out, float* prob_row0_out,
                  int32_t* topk_ids, float* topk_logprobs, float* row_stats);

@@ -101,7 +101,7 @@ SIGNATURES = {
     "mi_op_rope_append": (C.c_int, [C.POINTER(OpAttnShape), _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int]),
     "mi_op_attention": (C.c_int, [C.POINTER(OpAttnShape), _P, _P, _P, _P, _P, C.c_float, C.c_int, _P]),
     "mi_op_attention_decode": (C.c_int, [C.POINTER(OpAttnShape), _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, C.c_float,
-                                         C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float)]),
+                                         C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mi_op_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -95,6 +95,7 @@ struct mi_engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   int opt_force_v1 = 0;
   int opt_fused_attn = 1;
+  int opt_attn_mfma = 1;                 // decode attention on the matrix cores where the shape allows
   int opt_tile_weights = 1;
   int opt_prefill_gemm = 1;
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
@@ -363,6 +364,7 @@ int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L) {
   for (int b = 0; b < B; ++b) mx = std::max(mx, kv->h_off[b] + 1);
   int ns = (256 + B * Hkv - 1) / (B * Hkv);
   ns = std::min(ns, std::max(1, mx / 64));
+  ns = std::max(ns, (mx + 1023) / 1024);     // long contexts: at most four 256-key rounds per workgroup
   return std::max(1, std::min(ns, 16));
 }
 
@@ -428,7 +430,12 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
       // decode: norm + RoPE + append + attention + split combine in one launch
       Prof pr(e, "attn");
       AttnDecodeCall ac{s, e->qkv, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab,
-                        e->attn, 1.0f / sqrtf((float)D), RND_NONE, nsplit, kv->partial, kv->counters};
+                        e->attn, 1.0f / sqrtf((float)D), RND_NONE, nsplit, kv->partial, kv->counters,
+                        e->opt_attn_mfma ? 0 : 1};
+      if (B <= 32) {
+        ac.n_host_off = B;
+        for (int b = 0; b < B; ++b) ac.host_off[b] = kv->h_off[b];
+      }
       MI_TRY(launch_attention_decode(ac, st));
     } else {
       { Prof pr(e, "rope_append");
@@ -910,6 +917,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
   if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
   if (k == "prefill_gemm") { e->opt_prefill_gemm = value != 0; return MI_OK; }
+  if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "tile_weights") {
     if (e->finalized) return fail(MI_ERR_INVALID, "tile_weights must be set before mi_engine_finalize");

@@ -156,6 +156,9 @@ struct AttnDecodeCall {
   int nsplit;
   float* partial;          // [B*Hq][nsplit][D+2]
   int* counters;           // [B*Hkv] zero-initialised arrival tickets
+  int variant;             // 0: MFMA kernel where it applies (16-bit caches, D % 32 == 0); 1: VALU kernel
+  int n_host_off;          // > 0: host_off[0 .. B) holds the same values as *offsets (B <= 32)
+  int host_off[32];
 };
 int launch_attention_decode(const AttnDecodeCall& c, hipStream_t st);
 bool attention_decode_supported(const AttnShape& s);

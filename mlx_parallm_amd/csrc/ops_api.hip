@@ -131,11 +131,11 @@ int mi_op_attention(const mi_op_attn_shape* s, const void* q, const void* kcache
 int mi_op_attention_decode(const mi_op_attn_shape* s, const void* qkv, void* kcache, void* vcache,
                            const int32_t* offsets, const void* q_norm_w, const void* k_norm_w, float eps,
                            const float* cos_tab, const float* sin_tab, void* out, float scale, int rnd_out,
-                           int nsplit, float* partial, int32_t* counters, int iters, float* avg_ms) {
+                           int nsplit, float* partial, int32_t* counters, int variant, int iters, float* avg_ms) {
   if (!s) return fail(MI_ERR_INVALID, "null argument");
   MI_TRY(ready());
   AttnDecodeCall ac{to_shape(s), qkv, kcache, vcache, offsets, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
-                    out, scale, rnd_out, nsplit, partial, (int*)counters};
+                    out, scale, rnd_out, nsplit, partial, (int*)counters, variant};
   if (iters <= 1) {
     MI_TRY(launch_attention_decode(ac, nullptr));
     return finish();

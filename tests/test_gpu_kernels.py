@@ -266,6 +266,64 @@ def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
             assert close_frac(got, want, act, atol=1e-3) <= 0.02, close_frac(got, want, act, atol=1e-3)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("act", ["bfloat16", "float16", "float32"])
+@pytest.mark.parametrize("Hq,Hkv,D,qk_norm", [(8, 2, 128, False), (5, 1, 128, True), (4, 4, 64, True), (16, 2, 32, False)])
+def test_fused_decode_attention(act, Hq, Hkv, D, qk_norm, variant):
+    """mi_op_attention_decode: q/k norm + RoPE + KV append + attention + split combine in one launch,
+    MFMA (variant 0, 16-bit caches) and VALU (variant 1) kernels: ragged per-row context lengths up to
+    several 256-key rounds, 1 / 3 / 4 splits; the cache must receive exactly the new K / V row."""
+    if act == "float32" and variant == 0:
+        pytest.skip("the MFMA kernel is for 16-bit caches; float32 runs the VALU kernel either way")
+    B, cap, max_pos = 4, 720, 768
+    offs = [700, 0, 37, 300]
+    cos, sin, c_ref, s_ref = _rope_setup(D, max_pos, 1e6 if qk_norm else 1e4)
+    nqkv = (Hq + 2 * Hkv) * D
+    kc = round_to(RNG.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
+    vc = round_to(RNG.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
+    qkv = round_to(RNG.standard_normal((B, 1, nqkv)).astype(np.float32), act)
+    qn = round_to(1 + 0.1 * RNG.standard_normal(D).astype(np.float32), act)
+    kn = round_to(1 + 0.1 * RNG.standard_normal(D).astype(np.float32), act)
+    q = qkv[..., :Hq * D].reshape(B, 1, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].reshape(B, 1, Hkv, D)
+    v = qkv[..., (Hq + Hkv) * D:].reshape(B, 1, Hkv, D).transpose(0, 2, 1, 3)
+    if qk_norm:
+        q, _ = ref_model.rms_norm(q, act, qn, act, 1e-6)
+        k, _ = ref_model.rms_norm(k, act, kn, act, 1e-6)
+    pos = np.array([[o] for o in offs])
+    q = ref_model.rope(q.transpose(0, 2, 1, 3), act, pos, c_ref, s_ref)
+    k = ref_model.rope(k.transpose(0, 2, 1, 3), act, pos, c_ref, s_ref)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    want = np.zeros((B, Hq * D), np.float32)
+    for b in range(B):
+        kc_ref[b, :, offs[b]:offs[b] + 1] = k[b]
+        vc_ref[b, :, offs[b]:offs[b] + 1] = v[b]
+        n = offs[b] + 1
+        o, _ = ref_model.sdpa(q[b:b + 1], kc_ref[b:b + 1, :, :n], vc_ref[b:b + 1, :, :n], D ** -0.5, None, act, act)
+        want[b] = o[0].transpose(1, 0, 2).reshape(Hq * D)
+    s = attn_shape(B, 1, Hq, Hkv, D, act, act, 0, cap)
+    qkv_d, off_d = dev(qkv.reshape(B, nqkv), act), dev_i32(offs)
+    qn_d, kn_d = dev(qn, act), dev(kn, act)
+    for nsplit in (1, 3, 4):
+        kc_d, vc_d = dev(kc, act), dev(vc, act)
+        out = torch.zeros((B, Hq * D), dtype=qkv_d.dtype, device="cuda")
+        part = torch.zeros((B * Hq * nsplit * (D + 2),), dtype=torch.float32, device="cuda")
+        ctr = torch.zeros((B * Hkv,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        L.check(L.lib().mi_op_attention_decode(C.byref(s), ptr(qkv_d), ptr(kc_d), ptr(vc_d), ptr(off_d),
+                                               ptr(qn_d) if qk_norm else None, ptr(kn_d) if qk_norm else None, 1e-6,
+                                               ptr(cos), ptr(sin), ptr(out), float(D ** -0.5), 0, nsplit, ptr(part),
+                                               ptr(ctr), variant, 1, None))
+        _assert_close(host(kc_d), kc_ref, act, scale=2.0)
+        assert np.array_equal(host(vc_d), vc_ref)
+        assert not ctr.cpu().numpy().any()                 # tickets are handed back for the next launch
+        got = host(out)
+        if act == "float32":
+            assert np.allclose(got, want, rtol=1e-4, atol=2e-5), np.abs(got - want).max()
+        else:
+            assert close_frac(got, want, act, atol=2e-3) <= 0.02, (nsplit, close_frac(got, want, act, atol=2e-3))
+
+
 def _run_sampler(lg, temp, top_p, u, k=0):
     B, V = lg.shape
     t = dev(lg)

@@ -38,7 +38,8 @@ def server(tiny_dirs, tmp_path_factory):
     with open(log_path, "w", buffering=1) as lf:
         proc = subprocess.Popen(args, cwd=str(ROOT), stdout=lf, stderr=subprocess.STDOUT, text=True, env=env)
     base = f"http://127.0.0.1:{port}"
-    deadline = time.time() + 240
+    import fastapi, transformers, uvicorn  # noqa: F401,E401  (pages the child's imports in: a fresh box reads them cold)
+    deadline = time.time() + 600
     ok = False
     while time.time() < deadline and proc.poll() is None:
         try:

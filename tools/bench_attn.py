@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--layers", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--splits", default="1,2,4,8,16")
+    ap.add_argument("--variant", type=int, default=0, help="0: MFMA kernel, 1: VALU kernel")
     ap.add_argument("--no-combine", type=int, default=0, help="timing experiment: skip the ticket/combine tail")
     a = ap.parse_args()
     B, S, Hq, Hkv, D = a.B, a.S, a.Hq, a.Hkv, a.D
@@ -51,7 +52,7 @@ def main():
                 C.byref(sh), C.c_void_p(qkv.data_ptr()), C.c_void_p(kcs[i].data_ptr()), C.c_void_p(vcs[i].data_ptr()),
                 C.c_void_p(offs.data_ptr()), None, None, 1e-6, C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()),
                 C.c_void_p(out.data_ptr()), float(D ** -0.5), 0, ns, C.c_void_p(part.data_ptr()),
-                None if a.no_combine else C.c_void_p(ctr.data_ptr()), a.iters if a.layers == 1 else 2, C.byref(ms)))
+                None if a.no_combine else C.c_void_p(ctr.data_ptr()), a.variant, a.iters if a.layers == 1 else 2, C.byref(ms)))
             tot += ms.value
         avg = tot / a.layers
         print(f"nsplit={ns:3d}  {avg*1e3:8.1f} us   {kv_bytes/avg/1e6:8.1f} GB/s", flush=True)
