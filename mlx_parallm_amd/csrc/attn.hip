@@ -522,6 +522,7 @@ int launch_attention(const AttnCall& c, hipStream_t st) {
   if (s.Hq % s.Hkv != 0) return fail(MI_ERR_INVALID, "attention: Hq must be a multiple of Hkv");
   if (c.nsplit < 1 || (c.nsplit > 1 && (s.L != 1 || c.partial == nullptr)))
     return fail(MI_ERR_INVALID, "attention: bad split configuration");
+  if (s.L > 1 && c.variant != 1 && c.nsplit == 1 && attention_prefill_supported(s)) return launch_attention_prefill(c, st);
   if (s.act == MI_F32 && s.kv == MI_F32) return launch_attn_d<float, float>(c, st);
   if (s.act == MI_BF16 && s.kv == MI_BF16) return launch_attn_d<bf16, bf16>(c, st);
   if (s.act == MI_F16 && s.kv == MI_F16) return launch_attn_d<f16, f16>(c, st);

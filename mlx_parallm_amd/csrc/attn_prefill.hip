@@ -1,0 +1,228 @@
+// attn_prefill.hip -- causal attention of the prefill call (L > 1 new tokens per row) on the matrix cores.
+//
+// scaled_dot_product_attention(q, keys, values, scale, mask = create_additive_causal_mask_variable)
+// (llama.py:139-141, qwen3.py:111-113, base.py:6-40) over a cache that rope_append has already extended
+// with this call's K / V rows: query t of row b sees keys 0 .. offsets[b] + t (left padding is attended
+// like any other token, quirk Q1).
+//
+// Workgroup = one (row b, kv head, tile of 16 queries): its G = Hq/Hkv waves are the G query heads
+// of the group, so every wave needs exactly the same keys and the K / V blocks (32 keys) are staged
+// once in LDS for all of them (registers -> LDS, the next block's global loads in flight during the
+// current block's MFMAs; one barrier per block).  Per wave and block, as in the decode kernel
+// (attn_decode.hip): S^T = K Q^T with A = K fragments read contiguously from the [tile][kk][g][key]
+// image, B = Q^T held in registers; the eight scores of a lane are, after exp2, the B fragment of
+// O^T = V^T P, whose A fragments come out of the [16-d tile][key][16 d] image through
+// ds_read_b64_tr_b16.  Lane (c16 = query, g) owns the running max / sum of its query and
+// O[query][16 dt + 4g + r].  Tiles are launched heaviest (latest queries) first.
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace mi {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (std::is_same<T, bf16>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  T v[2] = {(T)a, (T)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+constexpr int QT = 16;      // queries per workgroup
+constexpr int KB = 32;      // keys per block
+
+template <typename T, int D, int G>
+__global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
+  static_assert(sizeof(T) == 2 && D % 32 == 0 && D <= 128, "16-bit activations / caches, head_dim 32..128");
+  constexpr int KK = D / 32, DT = D / 16, NT = G * 64;
+  constexpr int NPIECE = KB * D / 8;                  // 16-byte pieces of one K (or V) block
+  constexpr int NP = (NPIECE + NT - 1) / NT;          // per thread
+  constexpr int IMG = KB * D * 2;                     // bytes of one image
+  constexpr float LOG2E = 1.4426950408889634f;
+  const AttnShape& s = c.s;
+  const int qt = gridDim.x - 1 - blockIdx.x, bh = blockIdx.y;
+  const int b = bh / s.Hkv, kh = bh % s.Hkv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int off = c.offsets[b];
+  const int t0 = qt * QT;
+  const int tq = min(t0 + c16, s.L - 1);              // this lane's query (clamped; stores are guarded)
+  const int nk = off + min(t0 + QT, s.L);             // keys any query of the tile may see
+  const int nb = (nk + KB - 1) / KB;
+  const int h = kh * G + wave;
+
+  __shared__ __attribute__((aligned(16))) unsigned char kimg[2][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char vimg[2][IMG];
+
+  const T* kc = (const T*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+  const T* vc = (const T*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+
+  u32x4 kreg[NP], vreg[NP];
+  auto load_block = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = min(i * NT + tid, NPIECE - 1);
+      const int key = min(j * KB + piece / (D / 8), nk - 1), dc = piece % (D / 8);
+      kreg[i] = *(const u32x4*)(kc + (size_t)key * D + 8 * dc);
+      vreg[i] = *(const u32x4*)(vc + (size_t)key * D + 8 * dc);
+    }
+  };
+  auto store_block = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = i * NT + tid;
+      if (piece < NPIECE) {
+        const int key = piece / (D / 8), dc = piece % (D / 8);
+        // K: [16-key tile][kk][g][key & 15] x 16 B -- a fragment read of (tile, kk) is 1 KiB contiguous
+        *(u32x4*)(kimg[buf] + ((((key >> 4) * KK + (dc >> 2)) * 4 + (dc & 3)) * 16 + (key & 15)) * 16) = kreg[i];
+        // V: [16-d tile][key][16 d] (32-byte rows) for the transposed reads
+        *(u32x4*)(vimg[buf] + (size_t)(dc >> 1) * (KB * 32) + key * 32 + (dc & 1) * 16) = vreg[i];
+      }
+    }
+  };
+
+  load_block(0);
+  // Q^T fragments of this wave's head (B operand: column = query)
+  u32x4 qf[KK];
+  {
+    const T* qp = (const T*)c.q + ((size_t)b * s.L + tq) * s.Hq * D + (size_t)h * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const u32x4*)(qp + 32 * kk + 8 * g4);
+  }
+  store_block(0);
+  __syncthreads();
+
+  const float sc2 = c.scale * LOG2E;
+  const int qpos = off + t0 + c16;                    // key positions <= qpos are visible to this lane's query
+  float m_run = -1e30f, l_run = 0.f;
+  f32x4 accO[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) accO[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tq4 = c16 >> 2, tp = c16 & 3;
+
+  for (int j = 0; j < nb; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < nb) load_block(j + 1);                // uniform branch; the loads fly during this block's MFMAs
+    f32x4 sc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const u32x4 kf = *(const u32x4*)(kimg[buf] + (((t * KK + kk) * 4 + g4) * 16 + c16) * 16);
+        sc[t] = mfma16<T>(kf, qf[kk], sc[t]);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (j * KB + 16 * t + 4 * g4 + r) <= qpos;
+        sc[t][r] = ok ? sc[t][r] * sc2 : -INFINITY;
+        mx = fmaxf(mx, sc[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m_run, mx);
+    const float corr = __builtin_amdgcn_exp2f(m_run - mn);
+    m_run = mn;
+    l_run *= corr;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) accO[dt] *= corr;
+    float p[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - mn); l_run += p[t][r]; }
+    const u32x4 pf = {pack2<T>(p[0][0], p[0][1]), pack2<T>(p[0][2], p[0][3]), pack2<T>(p[1][0], p[1][1]), pack2<T>(p[1][2], p[1][3])};
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const unsigned char* a0 = vimg[buf] + (size_t)dt * (KB * 32) + (4 * g4 + tq4) * 32 + tp * 8;
+      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 32));
+      const uint32_t* w0 = (const uint32_t*)&v0;
+      const uint32_t* w1 = (const uint32_t*)&v1;
+      const u32x4 vf = {w0[0], w0[1], w1[0], w1[1]};
+      accO[dt] = mfma16<T>(vf, pf, accO[dt]);
+    }
+    if (j + 1 < nb) store_block(buf ^ 1);             // the other buffer: nobody reads it during this block
+    __syncthreads();
+  }
+
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (t0 + c16 < s.L) {
+    const float inv = 1.0f / l_run;
+    T* op = (T*)c.out + ((size_t)b * s.L + tq) * s.Hq * D + (size_t)h * D + 4 * g4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const u32x2 v = {pack2<T>(accO[dt][0] * inv, accO[dt][1] * inv), pack2<T>(accO[dt][2] * inv, accO[dt][3] * inv)};
+      *(u32x2*)(op + 16 * dt) = v;
+    }
+  }
+}
+
+template <typename T, int D, int G>
+int launch_pg(const AttnCall& c, hipStream_t st) {
+  const AttnShape& s = c.s;
+  const dim3 grid((s.L + QT - 1) / QT, s.B * s.Hkv), block(G * 64);
+  hipLaunchKernelGGL((attn_prefill_kernel<T, D, G>), grid, block, 0, st, c);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+template <typename T, int D>
+int launch_pd(const AttnCall& c, hipStream_t st) {
+  switch (c.s.Hq / c.s.Hkv) {
+    case 1: return launch_pg<T, D, 1>(c, st);
+    case 2: return launch_pg<T, D, 2>(c, st);
+    case 4: return launch_pg<T, D, 4>(c, st);
+    case 5: return launch_pg<T, D, 5>(c, st);
+    case 8: return launch_pg<T, D, 8>(c, st);
+  }
+  return fail(MI_ERR_UNSUPPORTED, "attention_prefill: Hq/Hkv must be 1, 2, 4, 5 or 8");
+}
+
+template <typename T>
+int launch_pt(const AttnCall& c, hipStream_t st) {
+  switch (c.s.D) {
+    case 32: return launch_pd<T, 32>(c, st);
+    case 64: return launch_pd<T, 64>(c, st);
+    case 128: return launch_pd<T, 128>(c, st);
+  }
+  return fail(MI_ERR_UNSUPPORTED, "attention_prefill: head_dim must be 32, 64 or 128");
+}
+
+}  // namespace
+
+bool attention_prefill_supported(const AttnShape& s) {
+  if (s.L < 2 || s.act != s.kv || (s.act != MI_BF16 && s.act != MI_F16) || s.rnd != RND_NONE) return false;
+  if (s.Hkv <= 0 || s.Hq % s.Hkv != 0) return false;
+  const int G = s.Hq / s.Hkv;
+  if (!(G == 1 || G == 2 || G == 4 || G == 5 || G == 8)) return false;
+  return s.D == 32 || s.D == 64 || s.D == 128;
+}
+
+int launch_attention_prefill(const AttnCall& c, hipStream_t st) {
+  if (!attention_prefill_supported(c.s)) return fail(MI_ERR_UNSUPPORTED, "attention_prefill: shape / dtype not supported");
+  if (c.nsplit != 1) return fail(MI_ERR_INVALID, "attention_prefill: no split-KV");
+  return c.s.act == MI_BF16 ? launch_pt<bf16>(c, st) : launch_pt<f16>(c, st);
+}
+
+}  // namespace mi

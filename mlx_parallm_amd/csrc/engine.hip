@@ -444,7 +444,8 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
         MI_TRY(launch_rope_append(rc, st)); }
       { Prof pr(e, "attn");
         AttnShape sa = s; sa.rnd = RND_NONE;  // SDPA output dtype = promote(q, kv): float32 in quirk mode
-        AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial};
+        AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial,
+                    e->opt_attn_mfma ? 0 : 1};
         MI_TRY(launch_attention(ac, st)); }
     }
     {

@@ -135,8 +135,12 @@ struct AttnCall {
   float scale;
   int nsplit;            // >1 only for L == 1
   float* partial;        // [B*L*Hq][nsplit][D+2] when nsplit > 1
+  int variant;           // 0: L > 1 goes to the MFMA prefill kernel where it applies; 1: always the VALU kernel
 };
 int launch_attention(const AttnCall& c, hipStream_t st);
+// causal prefill attention on the matrix cores (attn_prefill.hip); launch_attention dispatches to it
+bool attention_prefill_supported(const AttnShape& s);
+int launch_attention_prefill(const AttnCall& c, hipStream_t st);
 
 // fused decode step (L == 1): q/k norm + RoPE + KV append + split-KV attention + combine
 struct AttnDecodeCall {

@@ -205,7 +205,7 @@ def _rope_setup(D, max_pos, base=10000.0, scale=1.0):
 
 @pytest.mark.parametrize("act", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("Hq,Hkv,D,qk_norm", [(4, 4, 16, False), (8, 2, 64, True), (5, 1, 128, True)])
-@pytest.mark.parametrize("L_", [1, 6])
+@pytest.mark.parametrize("L_", [1, 6, 70])
 def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
     """q/k norm + RoPE + append, then attention over the cache, prefill (L>1) and decode (L=1, with
     and without split-KV), heterogeneous per-row offsets."""
