@@ -50,7 +50,7 @@ def pretty(name: str) -> str:
     if own:
         name = own.replace("bf16", "__bf16")
     if "_Accum" in name:   # rocprofv3's failed demangle of a <__bf16, true, ...> instantiation
-        base = name.split("<")[0]
+        base = name.split("<")[0].replace("void ", "").replace("mi::(anonymous namespace)::", "").replace("mi::", "")
         return {"gemm_tile_kernel": "gemm_tile_kernel<bf16,swiglu>"}.get(base, base + "<bf16,...>")
     n = name.replace("void ", "").replace("mi::(anonymous namespace)::", "").replace("mi::", "")
     n = re.sub(r"\(.*\)$", "", n).replace(" [clone .kd]", "").replace(".kd", "")
