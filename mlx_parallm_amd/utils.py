@@ -571,3 +571,8 @@ async def batch_generate_text(model, tokenizer, prompts: List[str], max_tokens: 
 
 
 batch_generate_text_util = batch_generate_text                                   # utils.py:1349
+
+
+# --------- on-disk formats (utils.py:759-980) live in convert.py; re-exported under the reference's names ---------
+from .convert import (MAX_FILE_SIZE_GB, convert, dequantize_model, make_shards, quantize_model, save_config,  # noqa: E402,F401
+                      save_weights)

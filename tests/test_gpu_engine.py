@@ -367,6 +367,75 @@ def test_lora_adapter_applied(tiny_dirs, tmp_path):
     model.engine.close()
 
 
+def test_converted_checkpoint_and_lora_hot_swap(tiny_dirs, tmp_path):
+    """a directory written by convert(quantize=True) loads and matches the oracle on the same
+    files; weight_updater swaps adapters on the live engine (adapters.safetensors + config, then adapter.npz)."""
+    import json
+
+    from safetensors.torch import save_file
+    import torch
+
+    from mlx_parallm_amd import convert as cv
+    from mlx_parallm_amd.weight_updater import apply_lora_update
+
+    src, cfg = tiny_dirs["llama_bf16_gqa"]
+    q4 = tmp_path / "q4"
+    cv.convert(src, str(q4), quantize=True, q_group_size=64, q_bits=4, dtype="bfloat16")
+    model = utils.load_model(str(q4), max_positions=256)
+    ref = ref_generate.load(str(q4), max_pos=256)
+    toks = _left_pad_prompts(cfg, 2, 7)
+    kv = model.engine.new_kv(2, capacity=16, kv_dtype="model")
+    got = model.engine.forward(toks, kv)
+    want = ref(toks, cache=ref.make_cache(2, paged=False))[:, -1]
+    assert np.abs(got - want).max() <= 0.08, np.abs(got - want).max()
+    kv.close()
+
+    H, nh, D = cfg["hidden_size"], cfg["num_attention_heads"], cfg["head_dim"]
+    rank, last = 8, cfg["num_hidden_layers"] - 1
+    rng = np.random.default_rng(9)
+
+    def factors(seed_scale):
+        a = (rng.uniform(-1, 1, (H, rank)) / np.sqrt(H)).astype(np.float32)
+        b = (rng.standard_normal((rank, nh * D)) * seed_scale).astype(np.float32)
+        return a, b
+
+    def logits():
+        kv2 = model.engine.new_kv(2, capacity=16, kv_dtype="model")
+        out = model.engine.forward(toks, kv2)
+        kv2.close()
+        return out
+
+    base = logits()
+    a1, b1 = factors(0.5)
+    ad1 = tmp_path / "ad1"
+    ad1.mkdir()
+    save_file({f"model.layers.{last}.self_attn.q_proj.lora_a": torch.from_numpy(a1),
+               f"model.layers.{last}.self_attn.q_proj.lora_b": torch.from_numpy(b1)}, str(ad1 / "adapters.safetensors"))
+    (ad1 / "adapter_config.json").write_text(json.dumps({
+        "fine_tune_type": "lora", "num_layers": 1,
+        "lora_parameters": {"rank": rank, "scale": 4.0, "dropout": 0.0, "keys": ["self_attn.q_proj"]}}))
+    apply_lora_update(model, str(ad1))
+    ref1 = ref_generate.load(str(q4), adapter_path=str(ad1), max_pos=256)
+    w1 = ref1(toks, cache=ref1.make_cache(2, paged=False))[:, -1]
+    l1 = logits()
+    assert np.abs(l1 - base).max() > 0.3 and np.abs(l1 - w1).max() <= 0.08
+
+    a2, b2 = factors(1.0)                                        # second adapter: npz, no config -> scale of the first is kept
+    ad2 = tmp_path / "ad2"
+    ad2.mkdir()
+    np.savez(ad2 / "adapter.npz", **{f"model.layers.{last}.self_attn.q_proj.lora_a": a2,
+                                     f"model.layers.{last}.self_attn.q_proj.lora_b": b2})
+    import threading
+    assert apply_lora_update(model, str(ad2), lock=threading.RLock()) == 1
+    save_file({f"model.layers.{last}.self_attn.q_proj.lora_a": torch.from_numpy(a2),
+               f"model.layers.{last}.self_attn.q_proj.lora_b": torch.from_numpy(b2)}, str(ad1 / "adapters.safetensors"))
+    ref2 = ref_generate.load(str(q4), adapter_path=str(ad1), max_pos=256)     # same factors, scale 4.0, through the oracle
+    w2 = ref2(toks, cache=ref2.make_cache(2, paged=False))[:, -1]
+    l2 = logits()
+    assert np.abs(l2 - l1).max() > 0.3 and np.abs(l2 - w2).max() <= 0.08
+    model.engine.close()
+
+
 def test_error_behaviour(tiny_dirs, tmp_path):
     with pytest.raises(utils.ModelNotFoundError):
         utils.load(str(tmp_path / "nope"))
