@@ -152,6 +152,16 @@ int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_
  * tokens sampled by the previous enqueued step (they never leave the device). */
 int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L,
                     const mi_sample_params* sp, int64_t* ticket);
+/* Continuous batching (server/main.py:1404-1726 admits requests between steps): the same step on a SUBSET of
+ * the cache's rows.  rows[n] are distinct row indices of `kv` (its batch = the number of slots); tokens_in is
+ * [n, L] in that order, or NULL to feed the tokens the previous step sampled -- then the previous step must have
+ * had the same n (and, for meaningful results, the same rows in the same order).  Rows not named are untouched,
+ * so a finished sequence's slot can be reset (mi_kv_reset_row) and prefilled with a new prompt (n = 1, L = its
+ * length) while the other slots keep decoding in their own steps.  Results come back in `rows` order. */
+int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, const int32_t* tokens_in, int L,
+                         const mi_sample_params* sp, int64_t* ticket);
+/* Forget the contents of one row (its length becomes 0); ordered behind the steps already enqueued. */
+int mi_kv_reset_row(mi_kv* kv, int row);
 /* Block until `ticket` has finished; copy out its results (same meaning as mi_decode_sample). */
 int mi_step_wait(mi_engine* e, int64_t ticket, int32_t* tokens_out, float* logprob_out,
                  float* prob_row0_out, int32_t* topk_ids, float* topk_logprobs);

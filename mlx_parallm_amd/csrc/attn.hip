@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
   const int b = row / s.L, t = row % s.L;
   const int lane = threadIdx.x;
   const int D = s.D, D2 = D / 2;
-  const int pos = c.offsets[b] + t;
+  const int kb = s.rows ? s.rows[b] : b;          // cache row of batch entry b (continuous batching: a subset of rows)
+  const int pos = c.offsets[kb] + t;
   const int nq = s.Hq * D;
   const AT* src = (const AT*)c.qkv + (size_t)row * (nq + 2 * s.Hkv * D) + (size_t)head * D;
   const bool is_q = head < s.Hq, is_k = !is_q && head < s.Hq + s.Hkv;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
 
   if (!is_q && !is_k) {  // values: plain append
     const int kh = head - s.Hq - s.Hkv;
-    KT* dst = (KT*)c.vcache + (((size_t)b * s.Hkv + kh) * s.cap + pos) * D;
+    KT* dst = (KT*)c.vcache + (((size_t)kb * s.Hkv + kh) * s.cap + pos) * D;
     for (int i = lane; i < D; i += 64) dst[i] = (KT)(float)src[i];
     return;
   }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
       dst[i] = (AT)o1; dst[i + D2] = (AT)o2;
     } else {
       const int kh = head - s.Hq;
-      KT* dst = (KT*)c.kcache + (((size_t)b * s.Hkv + kh) * s.cap + pos) * D;
+      KT* dst = (KT*)c.kcache + (((size_t)kb * s.Hkv + kh) * s.cap + pos) * D;
       // the 16-bit rounding of the model dtype happens before the (possibly wider) cache store
       dst[i] = (KT)to_f32((AT)o1); dst[i + D2] = (KT)to_f32((AT)o2);
     }
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnCall c) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, gq = lane >> 4;
   const int row = b * s.L + t;
-  const int n_keys = c.offsets[b] + t + 1;
+  const int kb = s.rows ? s.rows[b] : b;
+  const int n_keys = c.offsets[kb] + t + 1;
   const int chunk = (n_keys + c.nsplit - 1) / c.nsplit;
   const int s0 = split * chunk, s1 = min(n_keys, s0 + chunk);
 
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnCall c) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
   }
-  const KT* kbase = (const KT*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D + li * EPL;
-  const KT* vbase = (const KT*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D + li * EPL;
+  const KT* kbase = (const KT*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D + li * EPL;
+  const KT* vbase = (const KT*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D + li * EPL;
 
   constexpr int U = 2;
   for (int sb = s0 + 4 * wave + gq; sb < s1; sb += 16 * U) {

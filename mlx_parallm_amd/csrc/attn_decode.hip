@@ -85,7 +85,8 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
   const int li = lane & 15, gq = lane >> 4;
   // the host knows every row's length (it advances them itself); taking it from the kernel arguments
   // removes a dependent global load from the head of the chain
-  const int pos = c.n_host_off > 0 ? c.host_off[b] : c.offsets[b];
+  const int kb = c.n_host_off > 0 ? c.host_row[b] : (s.rows ? s.rows[b] : b);   // cache row of batch entry b
+  const int pos = c.n_host_off > 0 ? c.host_off[b] : c.offsets[kb];
   const int n_keys = pos + 1;
   const int chunk = (n_keys + c.nsplit - 1) / c.nsplit;
   const int s0 = split * chunk, s1 = min(n_keys, s0 + chunk);
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
 
   // ---- the K/V rows of the first block go out before anything else: they depend on nothing
   // but the offsets, and their latency then hides the q / k_new prologue
-  T* kc = (T*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
-  T* vc = (T*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+  T* kc = (T*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  T* vc = (T*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
   const int send = min(s1, pos);                 // cached keys of this split: [s0, send)
   const T* kbase = kc + li * EPL;
   const T* vbase = vc + li * EPL;
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c)
   const int c16 = li, g4 = gq;                   // MFMA view: column / lane group
   // the host knows every row's length (it advances them itself); taking it from the kernel arguments
   // removes a dependent global load from the head of the chain
-  const int pos = c.n_host_off > 0 ? c.host_off[b] : c.offsets[b];
+  const int kb = c.n_host_off > 0 ? c.host_row[b] : (s.rows ? s.rows[b] : b);   // cache row of batch entry b
+  const int pos = c.n_host_off > 0 ? c.host_off[b] : c.offsets[kb];
   // the pos cached keys are cut evenly over the splits (a 1024-key context = 4 x 256 = one round each); the
   // new key is merged by the last split from registers / LDS
   const int chunk = (pos + c.nsplit - 1) / c.nsplit;
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c)
   float* st_l = st_m + 9 * G;
   int& is_last_sh = *(int*)(st_l + 9 * G);       // (no static __shared__ in front of the dynamic region)
 
-  T* kc = (T*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
-  T* vc = (T*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+  T* kc = (T*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  T* vc = (T*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
   const int send = min(s0 + chunk, pos);         // cached keys of this split: [s0, send)
 
   // ---- the K fragments and V rows of the first round go out before anything else

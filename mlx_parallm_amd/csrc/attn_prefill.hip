@@ -59,7 +59,8 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
   const int b = bh / s.Hkv, kh = bh % s.Hkv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g4 = lane >> 4;
-  const int off = c.offsets[b];
+  const int kb = s.rows ? s.rows[b] : b;              // cache row of batch entry b
+  const int off = c.offsets[kb];
   const int t0 = qt * QT;
   const int tq = min(t0 + c16, s.L - 1);              // this lane's query (clamped; stores are guarded)
   const int nk = off + min(t0 + QT, s.L);             // keys any query of the tile may see
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
   __shared__ __attribute__((aligned(16))) unsigned char kimg[2][IMG];
   __shared__ __attribute__((aligned(16))) unsigned char vimg[2][IMG];
 
-  const T* kc = (const T*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
-  const T* vc = (const T*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
+  const T* kc = (const T*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  const T* vc = (const T*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
 
   u32x4 kreg[NP], vreg[NP];
   auto load_block = [&](int j) {

@@ -103,7 +103,8 @@ struct mi_engine {
                                          // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
   unsigned* d_seam_counter = nullptr;    // arrival counter of the in-launch seams (monotonic)
   int* d_seam_error = nullptr;           // set by a workgroup that gave up waiting at a seam
-  unsigned seam_base = 0;                // value of *d_seam_counter once every enqueued launch has run
+  unsigned seam_base = 0;
+  int last_n = 0;                        // rows of the last enqueued step (device-resident token feed)                // value of *d_seam_counter once every enqueued launch has run
   void* xn = nullptr;            // [rows][max(H, I)] normalised activations of the prefill GEMMs
 };
 
@@ -114,6 +115,7 @@ struct mi_kv {
   void* k = nullptr; void* v = nullptr;
   int32_t* d_off = nullptr;
   std::vector<int32_t> h_off;
+  int32_t* d_rows = nullptr;     // [B] scratch: cache rows of the current call (continuous batching)
   float* partial = nullptr; int partial_splits = 0;
   int* counters = nullptr;       // [B*Hkv] split-arrival tickets of the fused decode attention
 };
@@ -358,10 +360,10 @@ int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear
   return MI_OK;
 }
 
-int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L) {
+int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L, const int32_t* rows = nullptr) {
   if (L != 1) return 1;
   int mx = 0;
-  for (int b = 0; b < B; ++b) mx = std::max(mx, kv->h_off[b] + 1);
+  for (int b = 0; b < B; ++b) mx = std::max(mx, kv->h_off[rows ? rows[b] : b] + 1);
   int ns = (256 + B * Hkv - 1) / (B * Hkv);
   ns = std::min(ns, std::max(1, mx / 64));
   ns = std::max(ns, (mx + 1023) / 1024);     // long contexts: at most four 256-key rounds per workgroup
@@ -370,7 +372,8 @@ int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L) {
 
 // the model forward for B*L tokens already in e->d_tokens; logits of the requested rows end
 // up in e->logits (float32, [B][V] or [B*L][V]).
-int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool want_logits) {
+// `rows` (host, B distinct cache rows) = the call covers that subset of kv's rows, batch entry b <-> rows[b]
+int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool want_logits, const int32_t* rows = nullptr) {
   const mi_model_desc& d = e->d;
   const size_t R = (size_t)B * L;
   const bool quirk = kv->quirk;
@@ -381,9 +384,16 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
   const int nqkv = (Hq + 2 * Hkv) * D;
   hipStream_t st = e->stream;
 
+  auto row_of = [&](int b) { return rows ? rows[b] : b; };
   for (int b = 0; b < B; ++b)
-    if (kv->h_off[b] + L > kv->cap || kv->h_off[b] + L > d.max_positions)
+    if (kv->h_off[row_of(b)] + L > kv->cap || kv->h_off[row_of(b)] + L > d.max_positions)
       return fail(MI_ERR_INVALID, "forward: KV capacity / max_positions exceeded (call mi_kv_reserve)");
+  const int32_t* d_rows = nullptr;
+  if (rows) {
+    if (!kv->d_rows) MI_HIP(hipMalloc(&kv->d_rows, kv->B * sizeof(int32_t)));
+    MI_HIP(hipMemcpyAsync(kv->d_rows, rows, B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    d_rows = kv->d_rows;
+  }
 
   { Prof pr(e, "embed");
     EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
@@ -391,7 +401,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
 
   const size_t layer_elems = (size_t)kv->B * Hkv * kv->cap * D;
   const size_t kes = dtype_size(kv->dtype);
-  const int nsplit = choose_nsplit(kv, B, Hkv, L);
+  const int nsplit = choose_nsplit(kv, B, Hkv, L, rows);
   if (nsplit > 1) {
     const size_t need = R * Hq * nsplit * (D + 2);
     if (kv->partial == nullptr || kv->partial_splits < nsplit) {
@@ -423,7 +433,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     (void)in_norm;
     if (!qkv_done) MI_TRY(gemv_rows(e, lw.qkv, qkv_call(li), R, es, es, "gemv_qkv"));
     qkv_done = false;
-    AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap};
+    AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, d_rows};
     void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
     if (L == 1 && e->opt_fused_attn && attention_decode_supported(s)) {
@@ -434,7 +444,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
                         e->opt_attn_mfma ? 0 : 1};
       if (B <= 32) {
         ac.n_host_off = B;
-        for (int b = 0; b < B; ++b) ac.host_off[b] = kv->h_off[b];
+        for (int b = 0; b < B; ++b) { ac.host_row[b] = row_of(b); ac.host_off[b] = kv->h_off[row_of(b)]; }
       }
       MI_TRY(launch_attention_decode(ac, st));
     } else {
@@ -480,8 +490,8 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     if (all_pos) { c.x = e->h; c.ldx = H; MI_TRY(gemv_rows(e, head, c, R, es, sizeof(float), "gemv_head")); }
     else { c.x = (char*)e->h + (size_t)(L - 1) * H * es; c.ldx = L * H; MI_TRY(gemv_rows(e, head, c, B, es, sizeof(float), "gemv_head")); }
   }
-  MI_TRY(launch_advance_offsets(kv->d_off, B, L, st));
-  for (int b = 0; b < B; ++b) kv->h_off[b] += L;
+  MI_TRY(launch_advance_offsets(kv->d_off, d_rows, B, L, st));
+  for (int b = 0; b < B; ++b) kv->h_off[row_of(b)] += L;
   return MI_OK;
 }
 
@@ -745,7 +755,7 @@ void mi_kv_destroy(mi_kv* kv) {
   if (!kv) return;
   hipSetDevice(kv->e->device);
   hipStreamSynchronize(kv->e->stream);
-  hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->partial); hipFree(kv->counters);
+  hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->partial); hipFree(kv->counters); hipFree(kv->d_rows);
   delete kv;
 }
 
@@ -756,6 +766,15 @@ int mi_kv_reset(mi_kv* kv, int batch) {
   MI_HIP(hipMemsetAsync(kv->d_off, 0, kv->B * sizeof(int32_t), kv->e->stream));
   MI_HIP(hipStreamSynchronize(kv->e->stream));
   std::fill(kv->h_off.begin(), kv->h_off.end(), 0);
+  return MI_OK;
+}
+
+int mi_kv_reset_row(mi_kv* kv, int row) {
+  if (!kv) return fail(MI_ERR_INVALID, "null kv");
+  if (row < 0 || row >= kv->B) return fail(MI_ERR_INVALID, "mi_kv_reset_row: row out of range");
+  MI_HIP(hipSetDevice(kv->e->device));
+  MI_HIP(hipMemsetAsync(kv->d_off + row, 0, sizeof(int32_t), kv->e->stream));   // ordered behind the steps already enqueued
+  kv->h_off[row] = 0;
   return MI_OK;
 }
 
@@ -847,6 +866,7 @@ int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, in
   else MI_HIP(hipMemcpyAsync(e->d_tokens, e->d_next, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   MI_TRY(forward_device(e, kv, B, L, false, true));
   MI_TRY(run_sample(e, B, sp));
+  e->last_n = B;
   const int64_t t = e->next_ticket++;
   Slot& s = e->slots[t % NSLOT];
   s.B = B; s.topk = sp ? sp->top_logprobs : 0; s.ticket = t;
@@ -856,6 +876,40 @@ int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, in
   if (s.topk > 0) {
     MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)B * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)B * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  MI_HIP(hipEventRecord(s.ev, st));
+  *ticket = t;
+  return MI_OK;
+}
+
+int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, const int32_t* tokens_in, int L,
+                         const mi_sample_params* sp, int64_t* ticket) {
+  if (!e || !kv || !rows) return fail(MI_ERR_INVALID, "null argument");
+  if (n < 1 || n > kv->B) return fail(MI_ERR_INVALID, "mi_step_enqueue_rows: n must be in [1, batch of the kv]");
+  for (int i = 0; i < n; ++i) {
+    if (rows[i] < 0 || rows[i] >= kv->B) return fail(MI_ERR_INVALID, "mi_step_enqueue_rows: row out of range");
+    for (int j = 0; j < i; ++j) if (rows[j] == rows[i]) return fail(MI_ERR_INVALID, "mi_step_enqueue_rows: duplicate row");
+  }
+  MI_TRY(check_call(e, kv, kv->B, L));
+  if (!ticket) return fail(MI_ERR_INVALID, "null ticket");
+  if (!tokens_in && L != 1) return fail(MI_ERR_INVALID, "device-resident token feed needs L == 1");
+  if (!tokens_in && e->last_n != n) return fail(MI_ERR_INVALID, "device-resident token feed needs the row set of the previous step");
+  MI_TRY(ensure_workspace(e, (size_t)n * L, (size_t)n, std::max(n, kv->B)));
+  hipStream_t st = e->stream;
+  if (tokens_in) MI_TRY(upload_tokens(e, tokens_in, n, L));
+  else MI_HIP(hipMemcpyAsync(e->d_tokens, e->d_next, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  MI_TRY(forward_device(e, kv, n, L, false, true, rows));
+  MI_TRY(run_sample(e, n, sp));
+  e->last_n = n;
+  const int64_t t = e->next_ticket++;
+  Slot& s = e->slots[t % NSLOT];
+  s.B = n; s.topk = sp ? sp->top_logprobs : 0; s.ticket = t;
+  MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipMemcpyAsync(s.logprob, e->d_logprob, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipMemcpyAsync(s.prob0, e->d_prob0, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (s.topk > 0) {
+    MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)n * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)n * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
   }
   MI_HIP(hipEventRecord(s.ev, st));
   *ticket = t;

@@ -108,6 +108,8 @@ struct AttnShape {
   int kv;       // storage type of the caches
   int rnd;      // logical rounding of q, k (after norm / rope) and of the attention output
   int cap;      // cache capacity (tokens)
+  const int32_t* rows;  // device [B] or null: batch entry b lives in cache row rows[b] (continuous batching:
+                        // the call covers a subset of the cache's rows); offsets[] is indexed by cache row
 };
 struct RopeAppendCall {
   AttnShape s;
@@ -161,8 +163,9 @@ struct AttnDecodeCall {
   float* partial;          // [B*Hq][nsplit][D+2]
   int* counters;           // [B*Hkv] zero-initialised arrival tickets
   int variant;             // 0: MFMA kernel where it applies (16-bit caches, D % 32 == 0); 1: VALU kernel
-  int n_host_off;          // > 0: host_off[0 .. B) holds the same values as *offsets (B <= 32)
+  int n_host_off;          // > 0: host_off[b] = offsets[cache row of b], host_row[b] = that cache row (B <= 32)
   int host_off[32];
+  int host_row[32];
 };
 int launch_attention_decode(const AttnDecodeCall& c, hipStream_t st);
 bool attention_decode_supported(const AttnShape& s);
@@ -189,7 +192,7 @@ struct SampleCall {
 };
 int launch_sample(const SampleCall& c, hipStream_t st);
 
-int launch_advance_offsets(int32_t* offsets, int B, int L, hipStream_t st);
+int launch_advance_offsets(int32_t* offsets, const int32_t* rows, int B, int L, hipStream_t st);
 int launch_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int D, float base, float scale,
                        hipStream_t st);
 int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, size_t n, hipStream_t st);

@@ -332,9 +332,9 @@ __global__ void prob_row0_kernel(const float* logits, const float* row_stats, co
   if (b < B) out[b] = __expf(logits[tokens[b]] - row_stats[1]);
 }
 
-__global__ void advance_offsets_kernel(int32_t* offsets, int B, int L) {
+__global__ void advance_offsets_kernel(int32_t* offsets, const int32_t* rows, int B, int L) {
   const int i = threadIdx.x;
-  if (i < B) offsets[i] += L;
+  if (i < B) offsets[rows ? rows[i] : i] += L;
 }
 
 __global__ void rope_tables_kernel(float* cos_tab, float* sin_tab, int max_pos, int D2, double base, double scale) {
@@ -377,8 +377,8 @@ int launch_sample(const SampleCall& c, hipStream_t st) {
   return MI_OK;
 }
 
-int launch_advance_offsets(int32_t* offsets, int B, int L, hipStream_t st) {
-  hipLaunchKernelGGL(advance_offsets_kernel, dim3(1), dim3(64 * ((B + 63) / 64)), 0, st, offsets, B, L);
+int launch_advance_offsets(int32_t* offsets, const int32_t* rows, int B, int L, hipStream_t st) {
+  hipLaunchKernelGGL(advance_offsets_kernel, dim3(1), dim3(64 * ((B + 63) / 64)), 0, st, offsets, rows, B, L);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -113,6 +113,10 @@ class KVCache:
             raise ValueError("KVCache.reset with a different batch size: create a new cache")
         L.check(L.lib().mi_kv_reset(self._h, self.batch_size))
 
+    def reset_row(self, row: int) -> None:
+        """Forget one row (continuous batching: the slot of a finished sequence)."""
+        L.check(L.lib().mi_kv_reset_row(self._h, int(row)))
+
     def ensure(self, needed_tokens: int) -> None:
         """Grow in ``step``-token blocks like base.py:104-117 (contents are kept)."""
         cap = self.capacity
@@ -263,6 +267,27 @@ class Engine:
                                             C.byref(sp.c), C.byref(ticket)))
         self._last_B = kv.batch_size
         self._last_topk = sp.c.top_logprobs
+        return int(ticket.value)
+
+    def step_enqueue_rows(self, kv: KVCache, rows, tokens=None, sample: Optional[SampleArgs] = None) -> int:
+        """``mi_step_enqueue_rows``: one step on the cache rows ``rows`` only (continuous batching).  ``tokens``
+        (len(rows), L) or None = the tokens the previous step sampled (same rows, same order)."""
+        sp = sample or SampleArgs()
+        r = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1)
+        ticket = C.c_int64(-1)
+        offs = kv.offsets
+        if tokens is None:
+            tok_ptr, Lq = None, 1
+        else:
+            tok = _i32(tokens)
+            if tok.shape[0] != len(r):
+                raise ValueError("step_enqueue_rows: tokens must have one row per entry of rows")
+            tok_ptr, Lq = tok.ctypes.data_as(C.POINTER(C.c_int32)), tok.shape[1]
+        if len(r) == 0 or r.min() < 0 or r.max() >= kv.batch_size:
+            raise ValueError("step_enqueue_rows: row out of range")
+        kv.ensure(max(offs[int(i)] for i in r) + Lq)
+        L.check(L.lib().mi_step_enqueue_rows(self._h, kv._h, r.ctypes.data_as(C.POINTER(C.c_int32)), len(r), tok_ptr, Lq,
+                                             C.byref(sp.c), C.byref(ticket)))
         return int(ticket.value)
 
     def step_wait(self, ticket: int, batch_size: int, top_logprobs: int = 0):

@@ -367,6 +367,67 @@ def test_lora_adapter_applied(tiny_dirs, tmp_path):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_f32", "qwen3_bf16", "llama_q8_f16", "llama_q4_bf16"])
+def test_row_subset_steps_equal_independent_sequences(tiny_dirs, name):
+    """mi_step_enqueue_rows / mi_kv_reset_row (continuous batching): sequences admitted into different slots
+    at different times, decoded together in changing row sets, one slot recycled -- every sequence must produce
+    what it produces alone (rows are independent), i.e. the oracle's single-sequence greedy run."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    eng = model.engine
+    exact = name == "llama_f32"
+    V = cfg["vocab_size"]
+    prompts = {"A": RNG.integers(3, V, size=(1, 7)), "B": RNG.integers(3, V, size=(1, 5)), "C": RNG.integers(3, V, size=(1, 40))}
+
+    def alone(p, n):
+        cache = ref.make_cache(1, paged=False)
+        y, out, margins = p, [], []
+        for _ in range(n):
+            lg = ref(y, cache=cache)[:, -1]
+            top2 = np.sort(lg[0])[-2:]
+            margins.append(float(top2[1] - top2[0]))
+            y = np.argmax(lg, axis=-1)[:, None]
+            out.append(int(y[0, 0]))
+        return out, margins
+
+    kv = eng.new_kv(4, capacity=64, kv_dtype="model")
+    greedy = SampleArgs(temp=0.0)
+    got = {k: [] for k in prompts}
+
+    def step(rows, names, tokens):
+        res = eng.step_wait(eng.step_enqueue_rows(kv, rows, tokens, greedy), len(rows))
+        for nm, t in zip(names, res["tokens"]):
+            got[nm].append(int(t))
+        return res["tokens"]
+
+    step([2], ["A"], prompts["A"])                                  # admit A into slot 2
+    assert kv.offsets == [0, 0, 7, 0]
+    step([2], ["A"], [[got["A"][-1]]])                              # A decodes alone
+    step([0], ["B"], prompts["B"])                                  # admit B into slot 0
+    step([2, 0], ["A", "B"], [[got["A"][-1]], [got["B"][-1]]])      # both, explicit tokens (row set changed)
+    step([2, 0], ["A", "B"], None)                                  # same row set: tokens stay on the device
+    step([2, 0], ["A", "B"], None)
+    assert kv.offsets == [8, 0, 11, 0]
+    kv.reset_row(2)                                                 # A is done; its slot is recycled for C
+    assert kv.offsets == [8, 0, 0, 0]
+    step([2], ["C"], prompts["C"])
+    step([0, 2], ["B", "C"], [[got["B"][-1]], [got["C"][-1]]])      # other order of rows
+    step([0, 2], ["B", "C"], None)
+    for nm in prompts:
+        want, margins = alone(prompts[nm], len(got[nm]))
+        for i, (g, w) in enumerate(zip(got[nm], want)):
+            if g != w:
+                assert not exact and margins[i] <= 0.13, (nm, i, got[nm], want, margins[i])
+                break                                              # a near-tie flip changes the continuation
+    with pytest.raises(ValueError):
+        eng.step_enqueue_rows(kv, [1, 1], [[3], [4]], greedy)
+    with pytest.raises(ValueError):
+        eng.step_enqueue_rows(kv, [4], [[3]], greedy)
+    with pytest.raises(ValueError):
+        eng.step_enqueue_rows(kv, [0, 1, 2], None, greedy)          # device feed with a different row count
+    kv.close()
+    eng.close()
+
+
 def test_converted_checkpoint_and_lora_hot_swap(tiny_dirs, tmp_path):
     """a directory written by convert(quantize=True) loads and matches the oracle on the same
     files; weight_updater swaps adapters on the live engine (adapters.safetensors + config, then adapter.npz)."""
