@@ -87,6 +87,8 @@ typedef struct mi_sample_params {
   int32_t logprobs_at_temperature; /* 0: logprob / top-k logprobs are log_softmax(logits) (generate_step);
                                     * 1 and temperature > 0: log_softmax(logits / temperature), the distribution
                                     * the server's logprobs path reports (server/main.py:571-584) */
+  const float* row_temperature;    /* both NULL: `temperature` / `top_p` apply to every row.  Both [B]: per-row */
+  const float* row_top_p;          /* values (continuous batching, where requests with different settings share a step) */
 } mi_sample_params;
 
 #define MI_MAX_TOP_LOGPROBS 20

@@ -81,6 +81,7 @@ struct mi_engine {
   float* logits = nullptr; float* lora_t = nullptr;
   int32_t* d_tokens = nullptr; size_t d_tokens_cap = 0;
   int32_t* d_forced = nullptr; size_t d_forced_cap = 0;   // mi_score_tokens targets
+  float* d_rowpar = nullptr; size_t d_rowpar_cap = 0;     // per-row temperature | top_p of the current step
   int32_t* d_next = nullptr;      // tokens sampled by the last step [maxB]
   float* d_logprob = nullptr; float* d_prob0 = nullptr; float* d_rowstats = nullptr; float* d_uniforms = nullptr;
   int32_t* d_topk_ids = nullptr; float* d_topk_lp = nullptr;
@@ -524,6 +525,17 @@ int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* f
     MI_HIP(hipMemcpyAsync(e->d_bias_vals, sp->logit_bias_values, sp->n_logit_bias * sizeof(float), hipMemcpyHostToDevice, st));
   }
   if (sp->uniforms && !forced) MI_HIP(hipMemcpyAsync(e->d_uniforms, sp->uniforms, B * sizeof(float), hipMemcpyHostToDevice, st));
+  const bool per_row = sp->row_temperature != nullptr && sp->row_top_p != nullptr && !forced;
+  if (per_row) {
+    if ((size_t)B > e->d_rowpar_cap) {
+      MI_HIP(hipStreamSynchronize(st));
+      hipFree(e->d_rowpar);
+      MI_HIP(hipMalloc(&e->d_rowpar, 2 * (size_t)B * sizeof(float)));
+      e->d_rowpar_cap = B;
+    }
+    MI_HIP(hipMemcpyAsync(e->d_rowpar, sp->row_temperature, B * sizeof(float), hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(e->d_rowpar + B, sp->row_top_p, B * sizeof(float), hipMemcpyHostToDevice, st));
+  }
   Prof pr(e, "sample");
   SampleCall sc{};
   sc.logits = e->logits; sc.B = B; sc.V = e->d.vocab_size; sc.rnd = RND_NONE;
@@ -533,6 +545,8 @@ int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* f
   sc.uniforms = (sp->uniforms && !forced) ? e->d_uniforms : nullptr; sc.seed = sp->seed; sc.step = e->step_counter++;
   sc.top_logprobs = sp->top_logprobs;
   sc.lp_temp = sp->logprobs_at_temperature;
+  sc.row_temp = per_row ? e->d_rowpar : nullptr;
+  sc.row_top_p = per_row ? e->d_rowpar + B : nullptr;
   sc.tokens_out = e->d_next; sc.logprob_out = e->d_logprob; sc.prob_row0_out = forced ? nullptr : e->d_prob0;
   sc.topk_ids = e->d_topk_ids; sc.topk_logprobs = e->d_topk_lp; sc.row_stats = e->d_rowstats;
   return launch_sample(sc, st);
@@ -593,7 +607,7 @@ void mi_engine_destroy(mi_engine* e) {
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
-  hipFree(e->d_seam_counter); hipFree(e->d_seam_error);
+  hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {

@@ -183,6 +183,8 @@ struct SampleCall {
   int top_logprobs;
   int lp_temp;               // report logprobs under softmax(logits / temperature) (temperature > 0)
   const int32_t* forced;     // device [B] or null: teacher forcing -- score these ids instead of sampling (< 0: skip row)
+  const float* row_temp;     // device [B] or null: per-row temperature / top_p instead of the scalars
+  const float* row_top_p;
   int32_t* tokens_out;       // device [B]
   float* logprob_out;        // device [B]
   float* prob_row0_out;      // device [B]

@@ -240,6 +240,9 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   __shared__ Prefix sh_p;
   const int b = blockIdx.x, V = c.V;
   float* lg = c.logits + (size_t)b * V;
+  // per-row sampling parameters (continuous batching: every request keeps its own) or the call's scalars
+  const float temperature = c.row_temp ? c.row_temp[b] : c.temperature;
+  const float top_p = c.row_top_p ? c.row_top_p[b] : c.top_p;
 
   if (c.n_bias > 0) {  // logits[:, indices] += values (utils.py:346-349)
     for (int i = threadIdx.x; i < c.n_bias; i += ST) {
@@ -263,15 +266,15 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   const int forced = c.forced ? c.forced[b] : 0;
   if (c.forced) {
     if (forced >= 0 && forced < V) token = forced;
-  } else if (c.temperature != 0.f) {
-    const float inv_t = 1.0f / c.temperature;
+  } else if (temperature != 0.f) {
+    const float inv_t = 1.0f / temperature;
     // total mass Z (integer): target = +inf prefix
     Prefix all = find_prefix(lg, V, mx, inv_t, ~0ull, hist_m, hist_c, &sh_p);
     const unsigned long long Z = all.mass;
     Prefix kept = all;
     uint32_t keep_key = 0; int keep_tie = 0x7fffffff;
-    if (c.top_p > 0.f && c.top_p < 1.f) {
-      const unsigned long long tgt = (unsigned long long)((double)c.top_p * (double)Z);
+    if (top_p > 0.f && top_p < 1.f) {
+      const unsigned long long tgt = (unsigned long long)((double)top_p * (double)Z);
       kept = find_prefix(lg, V, mx, inv_t, tgt, hist_m, hist_c, &sh_p);
       keep_key = kept.kstar; keep_tie = kept.ntie;
       if (kept.count == 0) {  // top token alone exceeds top_p (reference: 0/0); keep top-1
@@ -296,8 +299,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   }
   // logprobs are reported as (lg - mx) * lp_scale - lp_lse: the plain log-softmax, or the one of logits / T
   float lp_scale = 1.0f, lp_lse = lse - mx;
-  if (c.lp_temp && c.temperature > 0.f) {
-    lp_scale = 1.0f / c.temperature;
+  if (c.lp_temp && temperature > 0.f) {
+    lp_scale = 1.0f / temperature;
     float st = 0.f;
     for (int i = threadIdx.x; i < V; i += ST) st += __expf((lg[i] - mx) * lp_scale);
     st = block_sum(st, sh_f);

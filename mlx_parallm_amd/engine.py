@@ -67,6 +67,16 @@ class SampleArgs:
             self._keep += [ids, vals]
         self.set_uniforms(uniforms)
 
+    def set_row_params(self, temps, top_ps) -> None:
+        """Per-row temperature / top_p (one entry per row of the step) instead of the scalars."""
+        t = np.ascontiguousarray(temps, dtype=np.float32)
+        p = np.ascontiguousarray(top_ps, dtype=np.float32)
+        if t.shape != p.shape or t.ndim != 1:
+            raise ValueError("set_row_params: temps and top_ps must be 1-D and of equal length")
+        self._row = (t, p)
+        self.c.row_temperature = t.ctypes.data_as(C.POINTER(C.c_float))
+        self.c.row_top_p = p.ctypes.data_as(C.POINTER(C.c_float))
+
     def set_uniforms(self, uniforms) -> None:
         if uniforms is None:
             self.c.uniforms = None

@@ -195,6 +195,7 @@ class ServerState:
         self.stream_slots = asyncio.Semaphore(max(1, config.max_concurrent_streams))
         self.tasks: List[asyncio.Task] = []
         self.model_id: Optional[str] = None
+        self.scheduler = None              # ContinuousScheduler when config.scheduler == "continuous"
 
 
 # ------------------------------------------------------------------------------------------
@@ -750,18 +751,30 @@ def create_app(config: Optional[ServerConfig] = None, *, model=None, tokenizer=N
             await asyncio.get_running_loop().run_in_executor(None, _load_initial_model, state)
         if config.scheduler not in ("default", "continuous"):
             log.warning("unknown scheduler %r; using 'default'", config.scheduler)
-        if config.scheduler == "continuous":
-            # admit-on-step needs per-row KV admission in the engine (not built yet): the
-            # windowed workers serve the same routes meanwhile, with no wait once a request is queued
-            log.warning("scheduler 'continuous' is served by the windowed batch workers in this build")
-        state.tasks = [asyncio.create_task(batch_processing_worker(state)),
-                       asyncio.create_task(streaming_batch_worker(state))]
+        rec = _loaded(state.model_id)
+        if config.scheduler == "continuous" and rec is not None:
+            # admit-on-step over the engine's row-subset steps (server/scheduler.py); every generation route
+            # goes through it, the windowed workers are not started
+            from .scheduler import ContinuousScheduler
+
+            state.scheduler = ContinuousScheduler(rec.model_instance, rec.tokenizer_instance,
+                                                  max_slots=config.max_batch_size, metrics=state.metrics)
+            state.scheduler.start()
+            state.tasks = []
+        else:
+            if config.scheduler == "continuous":
+                log.warning("scheduler 'continuous' needs a loaded model at start-up; using the windowed workers")
+            state.tasks = [asyncio.create_task(batch_processing_worker(state)),
+                           asyncio.create_task(streaming_batch_worker(state))]
         try:
             yield
         finally:
             for t in state.tasks:
                 t.cancel()
             await asyncio.gather(*state.tasks, return_exceptions=True)
+            if state.scheduler is not None:
+                await asyncio.get_running_loop().run_in_executor(None, state.scheduler.stop)
+                state.scheduler = None
 
     app = FastAPI(title="mlx_parallm_amd Server", version="0.1.0", lifespan=lifespan,
                   description="Batched generation server for the MI355X decode engine (mlx_parallm-compatible API).")
@@ -815,15 +828,19 @@ def create_app(config: Optional[ServerConfig] = None, *, model=None, tokenizer=N
                 raise HTTPException(status_code=400, detail="logprobs must be <= 20")
             async with state.engine_lock:
                 try:
-                    return await loop.run_in_executor(None, completion_with_logprobs, rec.model_instance, tok,
-                                                      request.model, request)
+                    return await loop.run_in_executor(None, _exclusive(state, completion_with_logprobs), rec.model_instance,
+                                                      tok, request.model, request)
                 except (ValueError, NotImplementedError) as e:
                     raise HTTPException(status_code=400, detail=str(e))
         if request.stream:
             if request.n is not None and request.n > 1:
                 raise HTTPException(status_code=400,
                                     detail="Streaming with n > 1 is not currently supported for completions.")
+            if state.scheduler is not None:
+                return StreamingResponse(_scheduled_completion_stream(state, request, tok), media_type="text/event-stream")
             return StreamingResponse(_completion_stream(state, request, rec), media_type="text/event-stream")
+        if state.scheduler is not None:
+            return await _scheduled_response(state, request, tok, request.model)
         qr = QueuedRequest(request)
         await state.request_queue.put(qr)
         return await wait_for(qr, "request")
@@ -833,14 +850,19 @@ def create_app(config: Optional[ServerConfig] = None, *, model=None, tokenizer=N
         rec = ready_record(request.model, 409)
         async with state.engine_lock:
             return await asyncio.get_running_loop().run_in_executor(
-                None, perplexity_of, rec.model_instance, rec.tokenizer_instance, request.model, request.text)
+                None, _exclusive(state, perplexity_of), rec.model_instance, rec.tokenizer_instance, request.model, request.text)
 
     @app.post("/v1/chat/completions", response_model=ChatCompletionResponse)
     async def create_chat_completion(request: ChatCompletionRequest):
-        ready_record(request.model, 500)
+        rec = ready_record(request.model, 500)
+        if request.stream and request.n is not None and request.n > 1:
+            raise HTTPException(status_code=400, detail="Streaming with n > 1 is not currently supported.")
+        if state.scheduler is not None:
+            tok = _wrap(rec.tokenizer_instance)
+            if request.stream:
+                return StreamingResponse(_scheduled_chat_stream(state, request, tok), media_type="text/event-stream")
+            return await _scheduled_response(state, request, tok, request.model)
         if request.stream:
-            if request.n is not None and request.n > 1:
-                raise HTTPException(status_code=400, detail="Streaming with n > 1 is not currently supported.")
             queued = StreamQueuedChat(request)
             await state.stream_queue.put(queued)
 
@@ -861,6 +883,128 @@ def create_app(config: Optional[ServerConfig] = None, *, model=None, tokenizer=N
         return await wait_for(qr, "chat request")
 
     return app
+
+
+def _exclusive(state: ServerState, fn: Callable) -> Callable:
+    """Run ``fn`` with the engine to itself: under the continuous scheduler that means between two of its steps."""
+    def run(*args):
+        if state.scheduler is None:
+            return fn(*args)
+        with state.scheduler.borrow_engine():
+            return fn(*args)
+    return run
+
+
+def _request_params(req: AnyRequest) -> Tuple[int, float, float]:
+    """Per-request sampling settings under the continuous scheduler (every sequence keeps its own); the chat
+    defaults are those of the streaming path (1024 tokens, main.py:709), completions carry theirs."""
+    if isinstance(req, ChatCompletionRequest):
+        return (int(req.max_tokens or 1024), float(req.temperature if req.temperature is not None else 0.7),
+                float(req.top_p if req.top_p is not None else 1.0))
+    return int(req.max_tokens), float(req.temperature), float(req.top_p)
+
+
+def _submit(state: ServerState, tok: TokenizerWrapper, text: str, req: AnyRequest, on_delta: Optional[Callable] = None):
+    """Queue one sequence; -> (future resolving to (text, n_prompt, n_completion, finish_reason), n_prompt)."""
+    loop = asyncio.get_running_loop()
+    fut: asyncio.Future = loop.create_future()
+    ids = _ids_of(tok, text)[0]
+    max_tokens, temp, top_p = _request_params(req)
+    parts: List[str] = []
+
+    def sink(seq, delta, reason):            # scheduler thread
+        if delta:
+            parts.append(delta)
+        if on_delta is not None and (delta or reason):
+            loop.call_soon_threadsafe(on_delta, delta, reason)
+        if reason is not None:
+            result = ("".join(parts), len(ids), len(seq.generated), reason)
+            loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(result))
+
+    try:
+        state.scheduler.submit(ids, max_tokens, temp, top_p, sink)
+    except ValueError as e:
+        raise HTTPException(status_code=400, detail=str(e))
+    return fut, len(ids)
+
+
+async def _scheduled_response(state: ServerState, request: AnyRequest, tok: TokenizerWrapper, model_name: str):
+    """Non-streaming completion / chat completion through the continuous scheduler: the n choices are n
+    sequences (the zero-width-space variation of the windowed path is not needed: rows sample independently)."""
+    n = request.n if request.n is not None else 1
+    if not isinstance(n, int) or n <= 0:
+        raise HTTPException(status_code=500, detail=f"Error processing request: Parameter 'n' must be a positive integer, got {request.n}")
+    try:
+        text = prompt_text_of(request, tok)
+    except Exception as e:
+        raise HTTPException(status_code=500, detail=f"Error processing request: {e}")
+    futs = [_submit(state, tok, text, request)[0] for _ in range(n)]
+    try:
+        results = await asyncio.wait_for(asyncio.gather(*futs), timeout=state.config.request_timeout_seconds)
+    except asyncio.TimeoutError:
+        raise HTTPException(status_code=504, detail="Request processing timed out.")
+    if any(r[3] == "error" for r in results):
+        raise HTTPException(status_code=500, detail="Error processing request: generation failed")
+    usage = CompletionUsage(prompt_tokens=results[0][1], completion_tokens=sum(r[2] for r in results),
+                            total_tokens=results[0][1] + sum(r[2] for r in results))
+    if isinstance(request, CompletionRequest):
+        return CompletionResponse(model=model_name, usage=usage, choices=[
+            CompletionChoice(text=r[0], index=i, finish_reason=r[3]) for i, r in enumerate(results)])
+    return ChatCompletionResponse(model=model_name, usage=usage, choices=[
+        ChatCompletionChoice(index=i, message=ChatMessage(role="assistant", content=r[0].strip()), finish_reason=r[3])
+        for i, r in enumerate(results)])
+
+
+async def _scheduled_events(state: ServerState, request: AnyRequest, tok: TokenizerWrapper) -> AsyncGenerator[Tuple[Optional[str], Optional[str]], None]:
+    """(delta, finish_reason) events of one sequence, as they are produced."""
+    q: asyncio.Queue = asyncio.Queue()
+    _submit(state, tok, prompt_text_of(request, tok), request, on_delta=lambda d, r: q.put_nowait((d, r)))
+    while True:
+        delta, reason = await q.get()
+        yield delta, reason
+        if reason is not None:
+            return
+
+
+async def _scheduled_chat_stream(state: ServerState, request: ChatCompletionRequest, tok: TokenizerWrapper) -> AsyncGenerator[str, None]:
+    cid = f"chatcmpl-{uuid.uuid4().hex[:28]}"
+    first = True
+    try:
+        async with state.stream_slots:
+            async for delta, reason in _scheduled_events(state, request, tok):
+                d = DeltaMessage()
+                if first and delta is not None:
+                    d.role, first = "assistant", False
+                if delta is not None:
+                    d.content = delta
+                yield _chunk_sse(cid, request.model, d, reason)
+    except Exception as e:
+        log.error("chat stream: %s", e, exc_info=True)
+        yield _error_sse(str(e))
+    finally:
+        yield "data: [DONE]\n\n"
+
+
+async def _scheduled_completion_stream(state: ServerState, request: CompletionRequest, tok: TokenizerWrapper) -> AsyncGenerator[str, None]:
+    rid = f"cmpl-{uuid.uuid4().hex[:29]}"
+
+    def sse(text: str, finish: Optional[str]) -> str:
+        c = CompletionResponse(id=rid, created=int(time.time()), model=request.model, usage=None,
+                               choices=[CompletionChoice(text=text, index=0, finish_reason=finish)])
+        return f"data: {c.model_dump_json(exclude_none=True)}\n\n"
+
+    try:
+        async with state.stream_slots:
+            async for delta, reason in _scheduled_events(state, request, tok):
+                if delta:
+                    yield sse(delta, None)
+                if reason is not None:
+                    yield sse("", reason if reason in ("stop", "length") else "stop")
+    except Exception as e:
+        log.error("completion stream: %s", e, exc_info=True)
+        yield _error_sse(str(e))
+    finally:
+        yield "data: [DONE]\n\n"
 
 
 async def _completion_stream(state: ServerState, request: CompletionRequest,

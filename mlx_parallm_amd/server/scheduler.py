@@ -1,0 +1,275 @@
+"""Continuous (admit-on-step) scheduler over the engine's row-subset steps.
+
+The reference's ``--scheduler continuous`` (server/main.py:1404-1726) unifies streaming and non-streaming
+requests in one batch and admits between batches by rebuilding it.  This scheduler keeps what that mode is
+for -- a request does not wait for the running batch to finish -- and does it on a slot model instead:
+
+  * the KV cache has ``max_slots`` rows; a sequence owns one row from admission to its last token;
+  * admission = reset the row, prefill the prompt on that row alone (no padding: other rows are not part
+    of the call, ``mi_step_enqueue_rows`` with n = 1), emit its first token;
+  * every decode step runs on exactly the rows that are alive, each with its own temperature / top_p
+    (``mi_sample_params.row_temperature / row_top_p``);
+  * while the row set is stable the next step is enqueued before the current one is read back, sampled tokens
+    stay on the device (the same one-step-ahead pipelining as generate_step, utils.py:420-427); when a sequence
+    finishes or a request is waiting, the step already in flight completes, its tokens for finished rows are
+    dropped, and the next step starts from explicit tokens on the new row set.
+
+The scheduler runs on its own thread and owns the engine while it steps; other users of the same engine
+(logprobs / echo / perplexity) take ``engine_mutex`` and are let in between steps.  Results are delivered
+through a per-sequence ``sink(sequence, delta_text, finish_reason)`` callback invoked on the scheduler thread.
+"""
+from __future__ import annotations
+
+import collections
+import itertools
+import logging
+import os
+import threading
+import time
+from typing import Callable, Deque, List, Optional
+
+import numpy as np
+
+from ..tokenizer_utils import NaiveStreamingDetokenizer, TokenizerWrapper
+
+log = logging.getLogger("mlx_parallm_amd.scheduler")
+
+Sink = Callable[["Sequence", Optional[str], Optional[str]], None]
+
+
+class Sequence:
+    _ids = itertools.count()
+
+    def __init__(self, prompt_ids, max_tokens: int, temp: float, top_p: float, sink: Sink, detok):
+        self.id = next(Sequence._ids)
+        self.prompt = np.ascontiguousarray(prompt_ids, dtype=np.int32).reshape(-1)
+        self.max_tokens = int(max_tokens)
+        self.temp, self.top_p = float(temp), float(top_p)
+        self.sink = sink
+        self.detok = detok
+        self.generated: List[int] = []
+        self.slot: Optional[int] = None
+        self.finished: Optional[str] = None
+        self.last_token = -1
+        self.t_submit = time.perf_counter()
+
+
+class ContinuousScheduler:
+    def __init__(self, model, tokenizer, max_slots: int = 8, kv_dtype: Optional[str] = None, capacity: int = 1024,
+                 metrics=None):
+        from ..engine import SampleArgs      # noqa: F401  (fail early if the library is missing)
+        from ..utils import DEFAULT_KV_DTYPE
+
+        self.model = model
+        self.tok = tokenizer if isinstance(tokenizer, TokenizerWrapper) else TokenizerWrapper(tokenizer)
+        self.max_slots = int(max_slots)
+        self.kv = model.engine.new_kv(self.max_slots, capacity=capacity, kv_dtype=kv_dtype or DEFAULT_KV_DTYPE)
+        self.slots: List[Optional[Sequence]] = [None] * self.max_slots
+        self.pending: Deque[Sequence] = collections.deque()
+        self.cv = threading.Condition()
+        self.engine_mutex = threading.Lock()
+        self._waiters = 0
+        self._stop = False
+        self._thread: Optional[threading.Thread] = None
+        self._seed = int.from_bytes(os.urandom(4), "little")
+        self.metrics = metrics
+        self.steps = 0                     # decode steps executed
+        self.prefills = 0
+        self.max_rows_seen = 0
+
+    # ------------------------------------------------------------------ client side (any thread)
+    def submit(self, prompt_ids, max_tokens: int, temp: float, top_p: float, sink: Sink) -> Sequence:
+        seq = Sequence(prompt_ids, max_tokens, temp, top_p, sink, NaiveStreamingDetokenizer(self.tok._tokenizer))
+        if len(seq.prompt) == 0:
+            raise ValueError("empty prompt")
+        if len(seq.prompt) + seq.max_tokens > self.model.engine.max_positions:
+            raise ValueError(f"prompt ({len(seq.prompt)}) + max_tokens ({seq.max_tokens}) exceeds the engine's "
+                             f"max_positions ({self.model.engine.max_positions})")
+        with self.cv:
+            self.pending.append(seq)
+            self.cv.notify_all()
+        return seq
+
+    def start(self) -> None:
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, name="mi355-scheduler", daemon=True)
+            self._thread.start()
+
+    def stop(self) -> None:
+        with self.cv:
+            self._stop = True
+            self.cv.notify_all()
+        if self._thread is not None:
+            self._thread.join(timeout=30)
+            self._thread = None
+        try:
+            self.kv.close()
+        except Exception:          # pragma: no cover
+            pass
+
+    class _Borrow:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            with self.s.cv:
+                self.s._waiters += 1
+                self.s.cv.notify_all()
+            self.s.engine_mutex.acquire()
+            return self
+
+        def __exit__(self, *exc):
+            with self.s.cv:
+                self.s._waiters -= 1
+            self.s.engine_mutex.release()
+
+    def borrow_engine(self):
+        """``with scheduler.borrow_engine(): ...`` -- exclusive use of the engine between two scheduler steps."""
+        return ContinuousScheduler._Borrow(self)
+
+    # ------------------------------------------------------------------ scheduler thread
+    def _emit(self, seq: Sequence, delta: Optional[str], reason: Optional[str]) -> None:
+        try:
+            seq.sink(seq, delta, reason)
+        except Exception:          # a broken consumer must not stop the batch
+            log.exception("sequence %d: sink failed", seq.id)
+
+    def _finish(self, seq: Sequence, reason: str) -> None:
+        seq.detok.finalize()
+        tail = seq.detok.last_segment
+        seq.finished = reason
+        self._emit(seq, tail if tail else None, reason)
+
+    def _on_token(self, seq: Sequence, tok: int) -> None:
+        eos = self.tok.eos_token_id
+        seq.last_token = tok
+        if tok == eos:
+            self._finish(seq, "stop")
+            return
+        seq.generated.append(tok)
+        seq.detok.add_token(tok)
+        delta = seq.detok.last_segment
+        if len(seq.generated) >= seq.max_tokens:
+            seq.detok.finalize()
+            tail = seq.detok.last_segment
+            seq.finished = "length"
+            self._emit(seq, (delta or "") + (tail or "") or None, "length")
+        elif delta:
+            self._emit(seq, delta, None)
+
+    def _sample_args(self, seqs: List[Sequence]):
+        from ..engine import SampleArgs
+
+        self._seed = (self._seed + 1) & 0xFFFFFFFF
+        sp = SampleArgs(temp=seqs[0].temp, top_p=seqs[0].top_p, seed=self._seed)
+        sp.set_row_params([s.temp for s in seqs], [s.top_p for s in seqs])
+        return sp
+
+    def _admit(self, seq: Sequence, slot: int) -> None:
+        eng = self.model.engine
+        seq.slot = slot
+        self.slots[slot] = seq
+        if seq.max_tokens <= 0:
+            self._finish(seq, "length")
+            return
+        self.kv.reset_row(slot)
+        t0 = time.perf_counter()
+        res = eng.step_wait(eng.step_enqueue_rows(self.kv, [slot], seq.prompt[None, :], self._sample_args([seq])), 1)
+        self.prefills += 1
+        if self.metrics is not None:
+            self.metrics.record_throughput({"prompt_tokens": float(len(seq.prompt)), "prompt_time": time.perf_counter() - t0})
+        self._on_token(seq, int(res["tokens"][0]))
+
+    def _release_finished(self) -> None:
+        for i, s in enumerate(self.slots):
+            if s is not None and s.finished:
+                self.slots[i] = None
+
+    def _run(self) -> None:
+        eng = self.model.engine
+        inflight = None                      # (ticket, seqs) of a decode step that has been enqueued but not read
+        sp_keep = []                         # SampleArgs of the steps in flight (their host arrays must stay alive)
+
+        def drain():
+            nonlocal inflight
+            if inflight is not None:
+                ticket, seqs = inflight
+                res = eng.step_wait(ticket, len(seqs))
+                for s, t in zip(seqs, res["tokens"]):
+                    if not s.finished:
+                        self._on_token(s, int(t))
+                inflight = None
+                sp_keep.clear()
+
+        while True:
+            with self.cv:
+                while not self._stop and not self.pending and inflight is None and not any(
+                        s is not None and not s.finished for s in self.slots) and self._waiters == 0:
+                    self.cv.wait(timeout=0.5)
+                if self._stop:
+                    break
+                if self._waiters > 0 and inflight is None:
+                    self.cv.wait(timeout=0.002)          # let the borrower take the mutex
+            try:
+                with self.engine_mutex:
+                    # ---- admissions: one prefill per new sequence, on its own row
+                    self._release_finished()
+                    while True:
+                        with self.cv:
+                            free = [i for i, s in enumerate(self.slots) if s is None]
+                            seq = self.pending.popleft() if (free and self.pending) else None
+                        if seq is None:
+                            break
+                        drain()
+                        self._admit(seq, free[0])
+                        self._release_finished()
+                    active = [s for s in self.slots if s is not None and not s.finished]
+                    if not active:
+                        drain()
+                        continue
+                    self.max_rows_seen = max(self.max_rows_seen, len(active))
+                    rows = [s.slot for s in active]
+                    t0 = time.perf_counter()
+                    if inflight is None:
+                        sp = self._sample_args(active)
+                        sp_keep.append(sp)
+                        inflight = (eng.step_enqueue_rows(self.kv, rows, [[s.last_token] for s in active], sp), active)
+                    # one step ahead while nothing asks for a change of the row set
+                    nxt = None
+                    with self.cv:
+                        stable = not self.pending and self._waiters == 0
+                    if stable and all(len(s.generated) + 2 <= s.max_tokens for s in active):
+                        sp = self._sample_args(active)
+                        sp_keep.append(sp)
+                        nxt = (eng.step_enqueue_rows(self.kv, rows, None, sp), active)
+                    ticket, seqs = inflight
+                    res = eng.step_wait(ticket, len(seqs))
+                    self.steps += 1
+                    for s, t in zip(seqs, res["tokens"]):
+                        if not s.finished:
+                            self._on_token(s, int(t))
+                    inflight = nxt
+                    if len(sp_keep) > 2:
+                        del sp_keep[0]
+                    if inflight is not None and any(s.finished for s in active):
+                        drain()                              # the row set changes: finish the step in flight first
+                    if self.metrics is not None:
+                        self.metrics.record_throughput({"decode_tokens": float(len(active)),
+                                                        "decode_time": time.perf_counter() - t0})
+                    with self.cv:
+                        must_yield = self._waiters > 0
+                    if must_yield:
+                        drain()
+            except Exception as e:          # engine failure: fail every sequence, keep the thread alive
+                log.exception("scheduler step failed")
+                inflight = None
+                for i, s in enumerate(self.slots):
+                    if s is not None and not s.finished:
+                        s.finished = "error"
+                        self._emit(s, f"\n\nError during generation: {e}", "error")
+                    self.slots[i] = None
+        # shutdown: anything still queued or running is cut
+        for s in list(self.pending) + [x for x in self.slots if x is not None]:
+            if not s.finished:
+                s.finished = "error"
+                self._emit(s, None, "error")

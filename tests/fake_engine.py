@@ -31,9 +31,30 @@ class FakeKV:
         self.closed = True
 
 
+class FakeSlotKV:
+    """KV handle for the row-subset API (continuous batching): one oracle cache of batch 1 per row."""
+
+    def __init__(self, engine, batch_size):
+        self.engine, self.batch_size = engine, batch_size
+        self.rows = [engine.ref.make_cache(1, paged=False) for _ in range(batch_size)]
+
+    @property
+    def offsets(self):
+        return [c[0].offsets[0] for c in self.rows]
+
+    def reset_row(self, row):
+        self.rows[row] = self.engine.ref.make_cache(1, paged=False)
+        self.engine.trace.append(("reset_row", row))
+
+    def close(self):
+        pass
+
+
 class FakeEngine:
     """step_enqueue computes eagerly (there is no device) but hands results out only through
     step_wait, and records the call order so tests can check the one-step-ahead pipelining."""
+
+    max_positions = 2048
 
     def __init__(self, ref_model):
         self.ref = ref_model
@@ -41,6 +62,38 @@ class FakeEngine:
         self._results = {}
         self._next = 0
         self._last_tokens = None
+
+    def new_kv(self, batch_size, capacity=256, kv_dtype="model", step=256):
+        return FakeSlotKV(self, batch_size)
+
+    def step_enqueue_rows(self, kv, rows, tokens=None, sample=None):
+        rows = [int(r) for r in rows]
+        if len(set(rows)) != len(rows) or min(rows) < 0 or max(rows) >= kv.batch_size:
+            raise ValueError("bad rows")
+        if tokens is None:
+            if self._last_tokens is None or len(self._last_tokens) != len(rows):
+                raise ValueError("device-resident token feed needs the row set of the previous step")
+            tokens = self._last_tokens
+            self.trace.append(("enqueue_rows", tuple(rows), "device-tokens"))
+        else:
+            tokens = np.asarray(tokens)
+            self.trace.append(("enqueue_rows", tuple(rows), tokens.shape))
+        c = sample.c
+        temps, top_ps = getattr(sample, "_row", ([float(c.temperature)] * len(rows), [float(c.top_p)] * len(rows)))
+        out = []
+        for i, r in enumerate(rows):
+            logits = self.ref(tokens[i:i + 1], cache=kv.rows[r])[:, -1]
+            u = None
+            if temps[i] != 0:
+                u = np.random.default_rng(int(c.seed) * 131 + self._next * 17 + i).random(1)
+            s = ref_sample.sample(logits, temp=float(temps[i]), top_p=float(top_ps[i]), uniforms=u)
+            out.append(int(s["tokens"][0, 0]))
+        self._last_tokens = np.asarray(out)[:, None]
+        t = self._next
+        self._next += 1
+        self._results[t] = {"tokens": np.asarray(out, dtype=np.int32), "logprobs": np.zeros(len(rows), np.float32),
+                            "probs_row0": np.zeros(len(rows), np.float32)}
+        return t
 
     def forward(self, tokens, kv, all_positions=False, want_logits=True):
         lg = self.ref(np.asarray(tokens), cache=kv.caches)

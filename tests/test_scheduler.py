@@ -1,0 +1,179 @@
+"""Continuous (admit-on-step) scheduler on CPU: the slot logic of server/scheduler.py and the server routes in
+``--scheduler continuous`` mode, with the device engine replaced by the oracle-backed fake."""
+import asyncio
+import json
+import threading
+import time
+
+import httpx
+import numpy as np
+import pytest
+
+from fake_engine import FakeModel
+from mlx_parallm_amd import utils
+from mlx_parallm_amd.server import main as srv
+from mlx_parallm_amd.server.scheduler import ContinuousScheduler
+from mlx_parallm_amd.server.state import model_registry
+from mlx_parallm_amd.tokenizer_utils import load_tokenizer
+from oracle import ref_generate
+
+MODEL_ID = "tiny-scheduler-model"
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    from mlx_parallm_amd.tiny_model import build_tiny_model
+
+    d = tmp_path_factory.mktemp("sched") / "tiny"
+    build_tiny_model(d, seed=6, vocab_size=320, hidden_size=32, layers=2, heads=2, kv_heads=2,
+                     intermediate_size=64, quantize_model=False, dtype="float32")
+    return str(d)
+
+
+@pytest.fixture()
+def parts(tiny):
+    utils._kv_pool._pool.clear()
+    model_registry.clear()
+    return FakeModel(tiny, max_pos=2048), load_tokenizer(tiny)
+
+
+def _alone(tiny, ids, n, eos):
+    """The oracle's greedy continuation of one sequence on its own: (token ids without EOS, finish reason)."""
+    ref = ref_generate.load(tiny, max_pos=2048)
+    out = []
+    for (t, _), _ in zip(ref_generate.generate_step(np.asarray(ids)[None], ref, paged=False), range(n)):
+        if int(t[0, 0]) == eos:
+            return out, "stop"
+        out.append(int(t[0, 0]))
+    return out, "length"
+
+
+def test_scheduler_sequences_equal_their_solo_runs_and_slots_are_recycled(tiny, parts):
+    model, tok = parts
+    sched = ContinuousScheduler(model, tok, max_slots=2)
+    sched.start()
+    done = {}
+    texts = {}
+    ev = threading.Event()
+
+    def sink_for(name):
+        def sink(seq, delta, reason):
+            texts.setdefault(name, []).append(delta or "")
+            if reason is not None:
+                done[name] = (list(seq.generated), reason)
+                if len(done) == 4:
+                    ev.set()
+        return sink
+
+    prompts = {"a": tok.encode("first request, a long one"), "b": tok.encode("second"), "c": tok.encode("third request"),
+               "d": tok.encode("the fourth")}
+    limits = {"a": 12, "b": 3, "c": 6, "d": 5}
+    sched.submit(prompts["a"], limits["a"], 0.0, 1.0, sink_for("a"))
+    sched.submit(prompts["b"], limits["b"], 0.0, 1.0, sink_for("b"))
+    time.sleep(0.3)                                   # c and d arrive while a / b are decoding; only 2 slots exist
+    sched.submit(prompts["c"], limits["c"], 0.0, 1.0, sink_for("c"))
+    sched.submit(prompts["d"], limits["d"], 0.0, 1.0, sink_for("d"))
+    assert ev.wait(timeout=120)
+    sched.stop()
+    eos = tok.eos_token_id
+    for name in prompts:
+        want, reason = _alone(tiny, prompts[name], limits[name], eos)
+        assert done[name] == (want, reason), name
+        assert "".join(texts[name]) == tok.decode(want)
+    tr = model.engine.trace
+    prefills = [e for e in tr if e[0] == "enqueue_rows" and e[2] != "device-tokens" and e[2][1] > 1]
+    assert len(prefills) == 4 and all(len(e[1]) == 1 for e in prefills)       # one unpadded prefill per sequence
+    assert any(e[0] == "enqueue_rows" and len(e[1]) == 2 for e in tr)          # two sequences share decode steps
+    assert any(e[0] == "enqueue_rows" and e[2] == "device-tokens" for e in tr)  # one-step-ahead on a stable row set
+    assert sum(1 for e in tr if e[0] == "reset_row") == 4 and sched.max_rows_seen == 2
+    with pytest.raises(ValueError):
+        ContinuousScheduler(model, tok, max_slots=1).submit([], 4, 0.0, 1.0, lambda *a: None)
+
+
+def test_per_row_sampling_parameters(tiny, parts):
+    """A greedy and a hot sequence share steps; the greedy one must still equal its solo greedy run."""
+    model, tok = parts
+    sched = ContinuousScheduler(model, tok, max_slots=2)
+    sched.start()
+    done, ev = {}, threading.Event()
+
+    def sink(name):
+        def f(seq, delta, reason):
+            if reason is not None:
+                done[name] = list(seq.generated)
+                if len(done) == 2:
+                    ev.set()
+        return f
+
+    p = tok.encode("same prompt for both")
+    sched.submit(p, 10, 0.0, 1.0, sink("greedy"))
+    sched.submit(p, 10, 1.5, 0.95, sink("hot"))
+    assert ev.wait(timeout=120)
+    sched.stop()
+    want, _ = _alone(tiny, p, 10, tok.eos_token_id)
+    assert done["greedy"] == want and done["hot"] != want
+
+
+async def _serving(parts, **cfg):
+    config = srv.ServerConfig(model_path=MODEL_ID, scheduler="continuous", **cfg)
+    app = srv.create_app(config, model=parts[0], tokenizer=parts[1], model_id=MODEL_ID)
+    return app
+
+
+def _events(text):
+    ev = [line[len("data: "):] for line in text.splitlines() if line.startswith("data: ")]
+    assert ev and ev[-1] == "[DONE]"
+    return [json.loads(e) for e in ev[:-1]]
+
+
+def test_server_routes_in_continuous_mode(tiny, parts):
+    model, tok = parts
+
+    async def go():
+        app = await _serving(parts, max_batch_size=3)
+        async with app.router.lifespan_context(app):
+            async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://s", timeout=120) as c:
+                state = app.state.server
+                assert state.scheduler is not None and not state.tasks
+                # more concurrent requests than slots: all finish, each equal to its solo greedy run
+                prompts = [f"Request {i}: say hello." for i in range(7)]
+                rs = await asyncio.gather(*[c.post("/v1/completions", json={
+                    "model": MODEL_ID, "prompt": p, "max_tokens": 4 + i, "temperature": 0.0}) for i, p in enumerate(prompts)])
+                for i, (p, r) in enumerate(zip(prompts, rs)):
+                    assert r.status_code == 200, r.text[:300]
+                    ids = np.asarray(tok._tokenizer([p], return_tensors="np")["input_ids"])[0]
+                    want, reason = _alone(tiny, ids, 4 + i, tok.eos_token_id)
+                    j = r.json()
+                    assert j["choices"][0]["text"] == tok.decode(want) and j["choices"][0]["finish_reason"] == reason
+                    assert j["usage"] == {"prompt_tokens": len(ids), "completion_tokens": len(want), "total_tokens": len(ids) + len(want)}
+                assert state.scheduler.max_rows_seen == 3
+                # n choices = n sequences; chat; streams
+                r = await c.post("/v1/completions", json={"model": MODEL_ID, "prompt": "two", "max_tokens": 5, "temperature": 0.9,
+                                                          "top_p": 0.9, "n": 2})
+                assert r.status_code == 200 and [ch["index"] for ch in r.json()["choices"]] == [0, 1]
+                r = await c.post("/v1/chat/completions", json={"model": MODEL_ID, "max_tokens": 5, "temperature": 0.0,
+                                                               "messages": [{"role": "user", "content": "hi"}]})
+                assert r.status_code == 200 and r.json()["choices"][0]["message"]["role"] == "assistant"
+                payload = {"model": MODEL_ID, "max_tokens": 6, "temperature": 0.0, "stream": True,
+                           "messages": [{"role": "user", "content": "In one sentence, describe a tree."}]}
+                ra, rb = await asyncio.gather(c.post("/v1/chat/completions", json=payload), c.post("/v1/chat/completions", json=payload))
+                ea, eb = _events(ra.text), _events(rb.text)
+                text = lambda ev: "".join(e["choices"][0]["delta"].get("content") or "" for e in ev)
+                assert text(ea) == text(eb) and ea[-1]["choices"][0]["finish_reason"] in ("stop", "length")
+                assert ea[0]["choices"][0]["delta"].get("role") == "assistant"
+                r = await c.post("/v1/completions", json={"model": MODEL_ID, "prompt": "stream me", "max_tokens": 5, "stream": True})
+                ev = _events(r.text)
+                assert ev[-1]["choices"][0]["finish_reason"] in ("stop", "length") and all(e["object"] == "text_completion" for e in ev)
+                # the engine is borrowed between steps for the logprobs path while a long generation runs
+                long_task = asyncio.create_task(c.post("/v1/completions", json={"model": MODEL_ID, "prompt": "keep going", "max_tokens": 40}))
+                await asyncio.sleep(0.05)
+                r = await c.post("/v1/completions", json={"model": MODEL_ID, "prompt": "Hello world", "max_tokens": 0, "logprobs": 1, "echo": True})
+                assert r.status_code == 200 and r.json()["choices"][0]["logprobs"]["tokens"]
+                r = await c.post("/v1/perplexity", json={"model": MODEL_ID, "text": "Hello world"})
+                assert r.status_code == 200 and r.json()["token_count"] > 0
+                assert (await long_task).status_code == 200
+                r = await c.post("/v1/completions", json={"model": MODEL_ID, "prompt": "x", "max_tokens": 2, "n": 0})
+                assert r.status_code == 500
+                m = (await c.get("/debug/metrics")).json()
+                assert m["decode_tokens_total"] > 0 and m["prompt_tokens_total"] > 0
+    asyncio.run(go())
