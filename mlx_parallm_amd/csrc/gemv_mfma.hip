@@ -140,18 +140,22 @@ __device__ __forceinline__ void store_elem(AT* p, AT v, bool write_through) {
   }
 }
 
+// nbuf = 2 when K spans several activation chunks: chunk c+1 is staged into the other buffer while chunk c's
+// MFMAs run (no staging bubble in the weight stream)
 template <int NW, int NA, bool Q4>
-__host__ __device__ constexpr size_t phase_lds_bytes(int kc, int MB) {
-  return (size_t)kc * MB * 2 + (Q4 ? (size_t)(kc / 64) * MB * 4 : 0) + (size_t)NW * NA * 64 * 4 * 4 + 16 * 4 +
+__host__ __device__ constexpr size_t phase_lds_bytes(int kc, int MB, int nbuf) {
+  return nbuf * ((size_t)kc * MB * 2 + (Q4 ? (size_t)(kc / 64) * MB * 4 : 0)) + (size_t)NW * NA * 64 * 4 * 4 + 16 * 4 +
          (size_t)NW * 16 * 4;
 }
+// (dense weights only: the int4 variants have no registers to spare for the in-loop staging pass)
+__host__ __device__ constexpr int phase_nbuf(int K, int kc, int MB, bool q4) { return (K > kc && MB == 8 && !q4) ? 2 : 1; }
 
 // One GEMV.  Work is cut into "batches": TB 16-row tiles x a KS-wide slice of K (KS = NW * UK * BK:
 // every wave issues UK 16-byte loads per tile per batch, ALL of them before it touches the
 // activations), so a workgroup has its whole batch -- 128 KiB for a dense bf16 tile at K = 4096 --
 // in flight at once.  The next batch is issued right after the MFMAs of the current one retire its
 // registers, i.e. before the cross-wave reduction and the epilogue, which keeps HBM busy across tiles.
-template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
+template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J, bool DB = false>
 struct Phase {
   static constexpr int NT = NW * 64;
   static constexpr int NA = SWIGLU ? 2 : 1;
@@ -161,10 +165,14 @@ struct Phase {
   static constexpr int KS = NW * UK * BK;       // k-span of a batch (4096 dense / 2048 SwiGLU / 4096 int4)
   // J = staging items per thread per activation row: 1 covers kc <= 8*NT (4096), 2 up to 8192
   using S = AT;                          // scale dtype == activation dtype on this path
+  static constexpr bool DBUF = DB;       // double-buffered activation chunks (see phase_nbuf); an instantiation of its own,
+                                         // so that the single-chunk kernels keep their register allocation
 
   const MfmaParams& p;
-  // LDS: [frag: kc*MB*2 B][sx: (kc/64)*MB floats (int4)][red: NW*NA*64 float4][rs: 16][red2: NW*16]
+  // LDS: nbuf x {[frag: kc*MB*2 B][sx: (kc/64)*MB floats (int4)]} [red: NW*NA*64 float4][rs: 16][red2: NW*16]
   u32x4* frag; float* sx; float* red; float* rs_sh; float* red2;
+  u32x4* frag_b[2]; float* sx_b[2]; int nbuf;
+  u32x4* frag_w; float* sx_w;          // the buffer stage_x writes (frag / sx = the buffer the MFMAs read)
   int tid, lane, wave, c16, g;
   const AT* x;
   // Work items of this workgroup: 16-row tiles dealt round-robin (tile = w + i*G), so that
@@ -179,9 +187,16 @@ struct Phase {
   f32x4 acc[NA][TB];
 
   __device__ __forceinline__ Phase(const MfmaParams& pp, unsigned char* smem) : p(pp) {
-    frag = (u32x4*)smem;
-    sx = (float*)(smem + (size_t)p.kc * MB * 2);
-    red = sx + (Q4 ? (p.kc / 64) * MB : 0);
+    nbuf = DB ? 2 : 1;
+    const size_t one = (size_t)p.kc * MB * 2 + (Q4 ? (size_t)(p.kc / 64) * MB * 4 : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned char* base = smem + (size_t)(i < nbuf ? i : 0) * one;
+      frag_b[i] = (u32x4*)base;
+      sx_b[i] = (float*)(base + (size_t)p.kc * MB * 2);
+    }
+    frag = frag_w = frag_b[0]; sx = sx_w = sx_b[0];
+    red = (float*)(smem + (size_t)nbuf * one);
     rs_sh = red + NW * NA * 64 * 4;
     red2 = rs_sh + 16;
     tid = threadIdx.x; lane = tid & 63; wave = tid >> 6; c16 = lane & 15; g = lane >> 4;
@@ -280,11 +295,11 @@ struct Phase {
               for (int i = 0; i < 8; ++i) e[i] = t2[i];
             }
           }
-          frag[frag_slot<Q4>(k8, m, MB)] = v;
+          frag_w[frag_slot<Q4>(k8, m, MB)] = v;
           if constexpr (Q4) {
             // 8 consecutive lanes hold the 8 pieces of one 64-wide quantisation group
             sum = lane8_sum(sum);
-            if ((k8 & 7) == 0) sx[(k8 >> 3) * MB + m] = sum;
+            if ((k8 & 7) == 0) sx_w[(k8 >> 3) * MB + m] = sum;
           }
         }
       }
@@ -480,17 +495,25 @@ struct Phase {
     prefetch_next_x<COH>(0, 0);
 
     // ================= this workgroup's tile batches
+    int cur = 0;                                // nbuf == 2: the buffer that holds the chunk being multiplied
     for (int tb = 0; tb < nbatch; ++tb) {
       zero_acc();
       for (int c = 0; c < nchunks; ++c) {
         const int cbase = c * p.kc, kend = min(p.K, cbase + p.kc);
-        if (staged != c) {
+        if ((!DBUF || nbuf == 1) && staged != c) {
           __syncthreads();                      // every wave is done reading the old fragments
           stage_x(cbase, kend - cbase);         // from the registers prefetched one chunk ago
           __syncthreads();
           staged = c;
           prefetch_next_x<COH>(c, tb);
         }
+        // nbuf == 2: the chunk that follows this one (possibly chunk 0 of the next tile) is staged into the
+        // other buffer in the middle of this chunk's first batch -- its x has been in registers since the
+        // chunk began -- so the weight stream never waits for a staging pass
+        const int nc = (c + 1) % nchunks;
+        const bool stage_next = DBUF && nbuf == 2 && !(nc == 0 && tb + 1 >= nbatch);
+        // (selects, not indexed loads: a dynamically indexed member array would push the whole struct to scratch)
+        frag_w = cur ? frag_b[0] : frag_b[1]; sx_w = cur ? sx_b[0] : sx_b[1];
         for (int k0 = cbase; k0 < kend; k0 += KS) {
           // the batch that follows this one in this workgroup's sequence
           int ntb = tb, nk0 = k0 + KS, nkend = kend;
@@ -509,7 +532,16 @@ struct Phase {
             __builtin_amdgcn_sched_barrier(0);
             issue_u(u, ntb, nk0, nkend);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DBUF) {
+              if (u == UK / 2 && k0 == cbase && stage_next) stage_x(nc * p.kc, min(p.kc, p.K - nc * p.kc));
+            }
           }
+        }
+        if (DBUF && stage_next) {
+          __syncthreads();                      // the next chunk's fragments are complete; this chunk's are free
+          cur ^= 1;
+          frag = cur ? frag_b[1] : frag_b[0]; sx = cur ? sx_b[1] : sx_b[0];
+          prefetch_next_x<COH>(nc, nc == 0 ? tb + 1 : tb);
         }
       }
       finish<WT>(tb);
@@ -518,10 +550,10 @@ struct Phase {
   }
 };
 
-template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
+template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J, bool DB>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Phase<AT, Q4, MB, SWIGLU, NW, J> ph(p, smem_raw);
+  Phase<AT, Q4, MB, SWIGLU, NW, J, DB> ph(p, smem_raw);
   if (ph.ntiles <= 0) return;
   ph.template run<false, false, false>();
 }
@@ -567,11 +599,11 @@ int cu_count() {
   return n_cu;
 }
 
-template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J>
+template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J, bool DB>
 int launch_j(const MfmaParams& p, hipStream_t st) {
-  auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU, NW, J>;
+  auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU, NW, J, DB>;
   constexpr int NA = SWIGLU ? 2 : 1;
-  const size_t lds = phase_lds_bytes<NW, NA, Q4>(p.kc, MB);
+  const size_t lds = phase_lds_bytes<NW, NA, Q4>(p.kc, MB, DB ? 2 : 1);
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = std::min(p.N / 16, cu_count());        // one workgroup per CU; items are dealt in-kernel
   if (g_ev_start != nullptr)   // measurement: dispatch-level begin/end timestamps of THIS kernel
@@ -584,8 +616,12 @@ int launch_j(const MfmaParams& p, hipStream_t st) {
 
 template <typename AT, bool Q4, int MB, bool SWIGLU, int NW>
 int launch_one(const MfmaParams& p, hipStream_t st) {
-  if (p.kc <= 8 * NW * 64) return launch_j<AT, Q4, MB, SWIGLU, NW, 1>(p, st);
-  return launch_j<AT, Q4, MB, SWIGLU, NW, 2>(p, st);
+  if constexpr (!Q4 && MB == 8) {
+    if (phase_nbuf(p.K, p.kc, MB, Q4) == 2)      // K spans several activation chunks: the double-buffered instantiation
+      return p.kc <= 8 * NW * 64 ? launch_j<AT, Q4, MB, SWIGLU, NW, 1, true>(p, st) : launch_j<AT, Q4, MB, SWIGLU, NW, 2, true>(p, st);
+  }
+  if (p.kc <= 8 * NW * 64) return launch_j<AT, Q4, MB, SWIGLU, NW, 1, false>(p, st);
+  return launch_j<AT, Q4, MB, SWIGLU, NW, 2, false>(p, st);
 }
 
 template <typename AT>
@@ -604,7 +640,7 @@ template <typename AT, bool Q4, int MB, bool SWB, int JA, int JB>
 int launch_pair_j(const MfmaParams& pa, const MfmaParams& pb, const SeamParams& seam, hipStream_t st) {
   constexpr int NW = 8;
   auto kern = gemv_pair_kernel<AT, Q4, MB, SWB, NW, JA, JB>;
-  const size_t lds = std::max(phase_lds_bytes<NW, 1, Q4>(pa.kc, MB), phase_lds_bytes<NW, SWB ? 2 : 1, Q4>(pb.kc, MB));
+  const size_t lds = std::max(phase_lds_bytes<NW, 1, Q4>(pa.kc, MB, 1), phase_lds_bytes<NW, SWB ? 2 : 1, Q4>(pb.kc, MB, 1));
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (g_ev_start != nullptr)
     hipExtLaunchKernelGGL(kern, dim3(cu_count()), dim3(NW * 64), lds, st, g_ev_start, g_ev_stop, 0, pa, pb, seam);
