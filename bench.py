@@ -180,7 +180,9 @@ def main():
     rng = np.random.default_rng(args.seed + 17 * rank)                 # each rank decodes its own shard
     prompts = rng.integers(0, cfg["vocab_size"], size=(B, ctx)).astype(np.int32)
     kv = engine.new_kv(B, capacity=cap, kv_dtype=args.kv_dtype)
-    greedy = SampleArgs(temp=0.0)
+    # greedy for the bf16 configurations (BASELINE configs 2, 4); top-p 0.9 at temperature 1 with
+    # log-probabilities for the int4 configuration (config 3).  `greedy` names the per-step sampler either way.
+    greedy = SampleArgs(temp=1.0, top_p=0.9, seed=args.seed) if quant_bits else SampleArgs(temp=0.0)
 
     # ---- prefill (timed separately: "prefill tok/s")
     engine.sync()
@@ -271,7 +273,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not quant_bits else "int4-g64 weights, bf16 activations",
             "data": "synthetic token ids; random-init weights N(0,0.02^2)",
             "config": {
-                "workload": f"{family} shape ({args.workload}), batch {B}/GPU, greedy decode from KV length {ctx}",
+                "workload": f"{family} shape ({args.workload}), batch {B}/GPU, "
+                            + ("top-p 0.9 / T=1 sampling with logprobs" if quant_bits else "greedy decode") + f" from KV length {ctx}",
                 "batch_per_gpu": B, "global_batch": B * world, "context": ctx,
                 "kv_dtype": "bf16" if args.kv_dtype == "model" else "float32 (PagedKVCache quirk mode)",
                 "parallelism": f"dp{world} (batch-sharded replicas, no collective in the decode step)",

@@ -134,6 +134,13 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950).  mlx_parallm_amd has no CPU or PyTorch fallback.")
+    try:
+        # PyTorch ships its own libamdhip64; whichever HIP runtime is mapped first serves the whole process.
+        # Map torch's before ours so that tensors handed to mi_engine_set_tensor and the engine share one
+        # runtime (the other order leaves torch without devices: "No HIP GPUs are available").
+        import torch  # noqa: F401
+    except Exception:          # torch is plumbing, not a requirement of the library itself
+        pass
     handle = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the library does not export it
