@@ -11,7 +11,7 @@ import subprocess
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = CSRC / "libmi355_decode.so"
+LIB_PATH = Path(os.environ.get("MLX_PARALLM_AMD_LIB") or (CSRC / "libmi355_decode.so"))   # (env: A/B another build)
 
 # dtype / enum constants (mirror of the headers)
 MI_F32, MI_BF16, MI_F16, MI_U32 = 0, 1, 2, 3

@@ -13,9 +13,10 @@
 //   * the split that owns the new position appends K/V and takes the new key from registers;
 //   * splits publish (max, sum, O) partials and take a ticket; the last arriver of a
 //     (sequence, kv-head) combines them (agent-scope release -> ticket -> acquire; nobody waits).
+#include <algorithm>
 #include <type_traits>
 
-#include "kernels.h"
+#include "gemv_phase.h"
 
 namespace mi {
 
@@ -396,8 +397,25 @@ __host__ __device__ constexpr size_t attn_mfma_lds_bytes() {
   return (size_t)8 * 32 * D * 2 + (size_t)(G + 1) * D * 2 + (size_t)9 * G * D * 4 + (size_t)2 * 9 * G * 4 + 16;
 }
 
-template <typename T, int D, int G, bool NORM>
-__global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+template <typename T>
+__device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
+  if (write_through)   // read by other workgroups of this same launch (attn_decode_o_kernel)
+    __hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+
+// The launch as a device function: `after_loads()` runs once the body's own first global loads are in flight;
+// WT: publish `out` write-through.  Every thread of the workgroup returns from it (no thread exits the kernel
+// inside).  The two hooks exist for hosting another phase in the same launch: o_proj + residual behind the
+// attention (its whole weight matrix fits the workgroups' prefetch registers) was built that way, bit-identical,
+// and measured SLOWER than two launches -- 36.7 us with the weights prefetched from `after_loads`, 33.7 us
+// prefetched after the attention, against 19.6 + 12.1 us: the per-CU memory queue is in order, so the 128 KiB
+// of weight loads per CU sit in front of every dependent load of the attention's latency chain.  Dropped.
+template <typename T, int D, int G, bool NORM, bool WT, class Hook>
+__device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, unsigned char* smem, Hook after_loads) {
   static_assert(sizeof(T) == 2 && D % 32 == 0 && D <= 128 && G <= 8, "16-bit caches, head_dim 32/64/96/128");
   constexpr int EPL = D / 16, NWV = 8, NW32 = EPL / 2;
   constexpr int KK = D / 32, DT = D / 16, NV = (32 * D * 2) / (64 * 16);   // K steps, 16-d tiles, 16-B V loads per lane
@@ -420,7 +438,6 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c)
   const int nq = s.Hq * D;
   const T* row = (const T*)c.qkv + (size_t)b * (nq + 2 * s.Hkv * D);
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* vimg = smem + (size_t)wave * (32 * D * 2);          // this wave's V image
   T* q_sh = (T*)(smem + (size_t)8 * 32 * D * 2);                      // [G + 1][D]: q heads, then the new key
   float* st_o = (float*)(smem + (size_t)8 * 32 * D * 2 + (size_t)(G + 1) * D * 2);   // [9][G][D]
@@ -474,12 +491,15 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { cs[e] = cp[e]; sn[e] = sp[e]; }
   }
+  uint32_t r0[NW32];
+  if constexpr (NORM) load_raw<NW32>((const T*)(is_k ? c.k_norm_w : c.q_norm_w) + li * EPL, r0);
+  __builtin_amdgcn_sched_barrier(0);
+  after_loads();                                 // every global load the prologue waits for is in the queue ahead of this
+  __builtin_amdgcn_sched_barrier(0);
   float x[EPL];
   raw_to_f32<T, EPL, NW32>(raw, x);
   if constexpr (NORM) {
-    uint32_t r0[NW32];
     float nw[EPL];
-    load_raw<NW32>((const T*)(is_k ? c.k_norm_w : c.q_norm_w) + li * EPL, r0);
     raw_to_f32<T, EPL, NW32>(r0, nw);
     float ss = 0.f;
 #pragma unroll
@@ -628,7 +648,7 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c)
     }
     const int h = kh * G + g;
     if (c.nsplit == 1) {
-      out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
+      store_out<T>(&out[(size_t)h * D + d], store_act<T>(O / L, c.rnd_out), WT);
     } else {
       float* pp = c.partial + (((size_t)b * s.Hq + h) * c.nsplit + split) * (D + 2);
       __hip_atomic_store(&pp[2 + d], O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,8 +683,14 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c)
       L = fmaf(li_, cw, L);
       O = fmaf(oi_, cw, O);
     }
-    out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
+    store_out<T>(&out[(size_t)h * D + d], store_act<T>(O / L, c.rnd_out), WT);
   }
+}
+
+template <typename T, int D, int G, bool NORM>
+__global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn_decode_mfma_body<T, D, G, NORM, false>(c, smem, NoHook{});
 }
 
 template <typename T, int D, int G, bool NORM>

@@ -337,9 +337,7 @@ bool can_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear
   return gemv_pair_supported(fa.W, a, fb.W, b);
 }
 
-int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear& fb, GemvCall b, size_t rows,
-              const char* prof) {
-  a.M = b.M = (int)rows;
+int ensure_seam(mi_engine* e) {          // arrival counter + error flag of the in-launch seams
   if (e->d_seam_counter == nullptr) {
     MI_HIP(hipMalloc(&e->d_seam_counter, sizeof(unsigned)));
     MI_HIP(hipMalloc(&e->d_seam_error, sizeof(int)));
@@ -347,6 +345,13 @@ int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear
     MI_HIP(hipMemsetAsync(e->d_seam_error, 0, sizeof(int), e->stream));
     e->seam_base = 0;
   }
+  return MI_OK;
+}
+
+int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear& fb, GemvCall b, size_t rows,
+              const char* prof) {
+  a.M = b.M = (int)rows;
+  MI_TRY(ensure_seam(e));
   const bool selected = !e->prof_name.empty() && e->prof_name == prof;
   Prof pr(e, selected ? "" : prof);
   if (selected) {
@@ -437,9 +442,11 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, d_rows};
     void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
+    // o_proj + residual (llama.py:143,188)
+    GemvCall co; co.x = e->attn; co.ldx = Hq * D; co.act = act; co.rnd = RND_NONE; co.epi = EPI_RESID;
+    co.resid = e->h; co.ldo = H;
     if (L == 1 && e->opt_fused_attn && attention_decode_supported(s)) {
       // decode: norm + RoPE + append + attention + split combine in one launch
-      Prof pr(e, "attn");
       AttnDecodeCall ac{s, e->qkv, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab,
                         e->attn, 1.0f / sqrtf((float)D), RND_NONE, nsplit, kv->partial, kv->counters,
                         e->opt_attn_mfma ? 0 : 1};
@@ -447,6 +454,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
         ac.n_host_off = B;
         for (int b = 0; b < B; ++b) { ac.host_row[b] = row_of(b); ac.host_off[b] = kv->h_off[row_of(b)]; }
       }
+      Prof pr(e, "attn");
       MI_TRY(launch_attention_decode(ac, st));
     } else {
       { Prof pr(e, "rope_append");
@@ -460,9 +468,6 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
         MI_TRY(launch_attention(ac, st)); }
     }
     {
-      // o_proj + residual (llama.py:143,188)
-      GemvCall co; co.x = e->attn; co.ldx = Hq * D; co.act = act; co.rnd = RND_NONE; co.epi = EPI_RESID;
-      co.resid = e->h; co.ldo = H;
       // post_attention_layernorm + gate|up + SwiGLU (llama.py:189,165)
       GemvCall cg; cg.x = e->h; cg.ldx = H; cg.act = act; cg.rnd = RND_NONE; cg.pro = PRO_NORM; cg.norm_w = post_norm;
       cg.eps = d.rms_norm_eps; cg.epi = EPI_SWIGLU; cg.out = e->act; cg.ldo = I; cg.pair_offset = I;

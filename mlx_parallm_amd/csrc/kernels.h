@@ -169,6 +169,7 @@ struct AttnDecodeCall {
 };
 int launch_attention_decode(const AttnDecodeCall& c, hipStream_t st);
 bool attention_decode_supported(const AttnShape& s);
+bool gemv_mfma_supported(const LinearW& W, const GemvCall& c);
 
 struct SampleCall {
   float* logits;         // [B][V] float32 (modified in place by logit_bias)
