@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-timing", action="store_true")
+    ap.add_argument("--greedy", action="store_true", help="greedy decode also for the int4 workloads (A/B of the sampler)")
     ap.add_argument("--profile-kernel", default="gemv_gate_up")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (A/B experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -182,7 +183,7 @@ def main():
     kv = engine.new_kv(B, capacity=cap, kv_dtype=args.kv_dtype)
     # greedy for the bf16 configurations (BASELINE configs 2, 4); top-p 0.9 at temperature 1 with
     # log-probabilities for the int4 configuration (config 3).  `greedy` names the per-step sampler either way.
-    greedy = SampleArgs(temp=1.0, top_p=0.9, seed=args.seed) if quant_bits else SampleArgs(temp=0.0)
+    greedy = SampleArgs(temp=1.0, top_p=0.9, seed=args.seed) if (quant_bits and not args.greedy) else SampleArgs(temp=0.0)
 
     # ---- prefill (timed separately: "prefill tok/s")
     engine.sync()

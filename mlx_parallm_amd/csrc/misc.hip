@@ -82,6 +82,30 @@ int launch_embed_wk(const LinearW& W, const EmbedCall& c, hipStream_t st) {
 // result does not depend on the order in which threads add.
 constexpr int ST = 1024;
 
+// f(value, index) over one row of logits.  A pass is latency-bound if every thread walks it one dependent 4-byte load
+// at a time (measured: ~9 us per pass over 32000 logits); 16-byte loads, two in flight per thread.
+template <class F>
+__device__ __forceinline__ void for_row(const float* lg, int V, F f) {
+  if ((V & 3) == 0 && (((uintptr_t)lg) & 15) == 0) {
+    const float4* p4 = (const float4*)lg;
+    const int n4 = V >> 2;
+    int i = threadIdx.x;
+    for (; i + ST < n4; i += 2 * ST) {
+      const float4 a = p4[i], b = p4[i + ST];
+      const int j = 4 * i, k = 4 * (i + ST);
+      f(a.x, j); f(a.y, j + 1); f(a.z, j + 2); f(a.w, j + 3);
+      f(b.x, k); f(b.y, k + 1); f(b.z, k + 2); f(b.w, k + 3);
+    }
+    if (i < n4) {
+      const float4 a = p4[i];
+      const int j = 4 * i;
+      f(a.x, j); f(a.y, j + 1); f(a.z, j + 2); f(a.w, j + 3);
+    }
+  } else {
+    for (int i = threadIdx.x; i < V; i += ST) f(lg[i], i);
+  }
+}
+
 __device__ __forceinline__ uint32_t order_key(float f) {  // larger float -> larger key
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -146,42 +170,97 @@ __device__ float philox_uniform(uint64_t seed, uint64_t step, uint32_t row) {
 // limit_tie = INT_MAX for "all".
 struct Prefix { uint32_t kstar; int ntie; unsigned long long mass; int count; };
 
+// Level-0 histogram (top 8 key bits) of the whole row, built once per row and shared by every descent.  The logits of
+// one row share a few exponents, i.e. a few level-0 bins: the adds are spread over 8 private copies (by lane) to cut
+// the same-address serialisation of the LDS atomics, then folded.
+struct Hist0 { unsigned long long m[256]; int c[256]; };
+
+__device__ void build_hist0(const float* lg, int V, float mx, float inv_t, unsigned long long (*pm)[8], int (*pc)[8],
+                            Hist0* h0) {
+  // [bin][copy]: the 8 copies of a bin are neighbours, i.e. on different LDS banks ([copy][bin] would put them 2 KiB
+  // apart -- all on one bank)
+  for (int i = threadIdx.x; i < 8 * 256; i += ST) { pm[i >> 3][i & 7] = 0; pc[i >> 3][i & 7] = 0; }
+  __syncthreads();
+  const int cp = threadIdx.x & 7;
+  for_row(lg, V, [&](float l, int) {
+    const int bin = order_key(l) >> 24;
+    atomicAdd(&pm[bin][cp], mass_fx(l, mx, inv_t));
+    atomicAdd(&pc[bin][cp], 1);
+  });
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    unsigned long long m = 0; int n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m += pm[threadIdx.x][k]; n += pc[threadIdx.x][k]; }
+    h0->m[threadIdx.x] = m; h0->c[threadIdx.x] = n;
+  }
+  __syncthreads();
+}
+
+// Which bin holds the element at which the descending cumulative mass (starting from `above`) first exceeds
+// `target`?  One wave scans the 256 bins from 255 down (4 bins per lane + a wave scan: two block barriers instead of
+// a block-wide scan); returns through out_sh: mass / count of everything above that bin, and the bin (-1: all fits).
+__device__ void select_bin(const unsigned long long* hist_m, const int* hist_c, unsigned long long above, int above_cnt,
+                           unsigned long long target, unsigned long long*, int*, int*, Prefix* out_sh) {
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int L = threadIdx.x;
+    unsigned long long m[4], tm = 0; int c[4], tc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[j] = hist_m[255 - (4 * L + j)]; c[j] = hist_c[255 - (4 * L + j)]; tm += m[j]; tc += c[j]; }
+    unsigned long long im = tm; int ic = tc;                       // inclusive scan over lanes = descending bins
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long om = __shfl_up(im, off, 64);
+      const int oc = __shfl_up(ic, off, 64);
+      if (L >= off) { im += om; ic += oc; }
+    }
+    unsigned long long cum = above + im - tm; int cnt = above_cnt + ic - tc;
+    int pos = 256; unsigned long long pm = 0; int pc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (pos == 256) {
+        if (c[j] > 0 && cum + m[j] > target) { pos = 4 * L + j; pm = cum; pc = cnt; }
+        else { cum += m[j]; cnt += c[j]; }
+      }
+    }
+    int best = pos;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+    if (best == 256) { if (L == 63) { out_sh->mass = cum; out_sh->count = cnt; out_sh->ntie = -1; } }
+    else if (pos == best) { out_sh->mass = pm; out_sh->count = pc; out_sh->ntie = 255 - best; }
+  }
+  __syncthreads();
+}
+
+// Find the descending-order prefix whose cumulative mass is <= target (radix descent over the order key, 8 bits per
+// level; level 0 comes from the cached histogram, the lower levels touch only the elements under the chosen prefix).
 __device__ Prefix find_prefix(const float* lg, int V, float mx, float inv_t, unsigned long long target,
-                              unsigned long long* hist_m, int* hist_c, Prefix* out_sh) {
+                              unsigned long long* hist_m, int* hist_c, Prefix* out_sh, const Hist0* h0,
+                              unsigned long long* sc_m, int* sc_c, int* sel) {
   uint32_t prefix_bits = 0;   // fixed high bits of kstar so far
   uint32_t prefix_mask = 0;
   unsigned long long above = 0;  // mass of keys strictly greater than the current candidate bin
   int above_cnt = 0;
   for (int level = 0; level < 4; ++level) {
     const int shift = 24 - 8 * level;
-    __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += ST) { hist_m[i] = 0; hist_c[i] = 0; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < V; i += ST) {
-      const float l = lg[i];
-      const uint32_t k = order_key(l);
-      if ((k & prefix_mask) == prefix_bits) {
-        const int bin = (k >> shift) & 255;
-        atomicAdd(&hist_m[bin], mass_fx(l, mx, inv_t));
-        atomicAdd(&hist_c[bin], 1);
-      }
+    if (level == 0) {
+      select_bin(h0->m, h0->c, above, above_cnt, target, sc_m, sc_c, sel, out_sh);
+    } else {
+      __syncthreads();
+      for (int i = threadIdx.x; i < 256; i += ST) { hist_m[i] = 0; hist_c[i] = 0; }
+      __syncthreads();
+      for_row(lg, V, [&](float l, int) {
+        const uint32_t k = order_key(l);
+        if ((k & prefix_mask) == prefix_bits) {
+          const int bin = (k >> shift) & 255;
+          atomicAdd(&hist_m[bin], mass_fx(l, mx, inv_t));
+          atomicAdd(&hist_c[bin], 1);
+        }
+      });
+      __syncthreads();
+      select_bin(hist_m, hist_c, above, above_cnt, target, sc_m, sc_c, sel, out_sh);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long cum = above;
-      int cnt = above_cnt;
-      int bin = 255;
-      for (; bin >= 0; --bin) {
-        if (hist_c[bin] == 0) continue;
-        if (cum + hist_m[bin] > target) break;   // this bin holds the crossing element
-        cum += hist_m[bin];
-        cnt += hist_c[bin];
-      }
-      out_sh->mass = cum;
-      out_sh->count = cnt;
-      out_sh->ntie = bin;  // -1: everything fits
-    }
-    __syncthreads();
     above = out_sh->mass;
     above_cnt = out_sh->count;
     const int bin = out_sh->ntie;
@@ -210,14 +289,69 @@ __device__ Prefix find_prefix(const float* lg, int V, float mx, float inv_t, uns
   return r;
 }
 
-// index of the (rank)-th smallest token id among those whose key == kstar
-__device__ int nth_tie(const float* lg, int V, uint32_t kstar, int rank, int* sh_i) {
+// index of the (rank)-th smallest token id among those whose key == kstar.
+// 16-bit logits make big tie groups (hundreds of ids share one value), so rank can be large: ONE counting pass
+// in index order (chunks of 4 * ST ids, thread t of chunk j owns ids 4 * (ST * j + t) .. + 3; per-(chunk, wave)
+// tie counts via ballots), a scan of that small table, and the owning wave finds the id among its 256.
+constexpr int TIE_TBL = 1024;       // (chunk, wave) entries: V <= 4 * ST * (TIE_TBL / 16) = 262144 ids
+__device__ int nth_tie(const float* lg, int V, uint32_t kstar, int rank, int* sh_i, int* tbl, int* found) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = (V + 4 * ST - 1) / (4 * ST);
+  const bool vec = (V & 3) == 0 && (((uintptr_t)lg) & 15) == 0 && nch * (ST / 64) <= TIE_TBL;
+  if (vec) {
+    auto ties_of = [&](int j, bool (&is)[4]) {
+      const int base = 4 * (ST * j + (int)threadIdx.x);
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (base < V) v = *(const float4*)(lg + base);
+      is[0] = base < V && order_key(v.x) == kstar; is[1] = base < V && order_key(v.y) == kstar;
+      is[2] = base < V && order_key(v.z) == kstar; is[3] = base < V && order_key(v.w) == kstar;
+    };
+    for (int j = 0; j < nch; ++j) {
+      bool is[4];
+      ties_of(j, is);
+      int n = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) n += __popcll(__ballot(is[e]));
+      if (lane == 0) tbl[j * (ST / 64) + wave] = n;
+    }
+    if (threadIdx.x == 0) *found = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // (chunk, wave) that holds the rank-th tie, and the rank inside it
+      int left = rank, at = -1;
+      for (int i = 0; i < nch * (ST / 64); ++i) {
+        const int n = tbl[i];
+        if (left < n) { at = i; break; }
+        left -= n;
+      }
+      sh_i[0] = at; sh_i[1] = left;
+    }
+    __syncthreads();
+    const int at = sh_i[0], left = sh_i[1];
+    if (at >= 0 && wave == at % (ST / 64)) {
+      bool is[4];
+      ties_of(at / (ST / 64), is);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      int before = 0, own = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { before += __popcll(__ballot(is[e]) & lt); own += is[e] ? 1 : 0; }
+      if (left >= before && left < before + own) {
+        int k = left - before;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (is[e]) { if (k == 0) *found = 4 * (ST * (at / (ST / 64)) + (int)threadIdx.x) + e; --k; }
+      }
+    }
+    __syncthreads();
+    const int r = *found;
+    __syncthreads();
+    return r;                                     // -1: fewer than rank + 1 ties (the caller falls back to the arg-max)
+  }
   int last = -1;
   for (int r = 0; r <= rank; ++r) {
     int best = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += ST)
-      if (i > last && i < best && order_key(lg[i]) == kstar) best = i;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for_row(lg, V, [&](float l, int i) {
+      if (i > last && i < best && order_key(l) == kstar) best = i;
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
     __syncthreads();
@@ -238,6 +372,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   __shared__ unsigned long long hist_m[256];
   __shared__ int hist_c[256];
   __shared__ Prefix sh_p;
+  __shared__ unsigned long long priv_m[256][8], sc_m[256];
+  __shared__ int priv_c[256][8], sc_c[256], sel_sh;
+  __shared__ Hist0 h0;
+  __shared__ int tie_tbl[TIE_TBL];
   const int b = blockIdx.x, V = c.V;
   float* lg = c.logits + (size_t)b * V;
   // per-row sampling parameters (continuous batching: every request keeps its own) or the call's scalars
@@ -253,11 +391,11 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   }
   // ---- max / argmax, log-sum-exp
   ArgMax a{-INFINITY, 0x7fffffff};
-  for (int i = threadIdx.x; i < V; i += ST) a = am_better(a, ArgMax{lg[i], i});
+  for_row(lg, V, [&](float l, int i) { a = am_better(a, ArgMax{l, i}); });
   a = block_argmax(a, sh_am);
   const float mx = a.v;
   float se = 0.f;
-  for (int i = threadIdx.x; i < V; i += ST) se += __expf(lg[i] - mx);
+  for_row(lg, V, [&](float l, int) { se += __expf(l - mx); });
   se = block_sum(se, sh_f);
   const float lse = mx + __logf(se);
   if (threadIdx.x == 0 && c.row_stats) { c.row_stats[2 * b] = mx; c.row_stats[2 * b + 1] = lse; }
@@ -269,13 +407,16 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   } else if (temperature != 0.f) {
     const float inv_t = 1.0f / temperature;
     // total mass Z (integer): target = +inf prefix
-    Prefix all = find_prefix(lg, V, mx, inv_t, ~0ull, hist_m, hist_c, &sh_p);
+    // total mass Z (integer) = sum of the level-0 histogram, which every descent below reuses
+    build_hist0(lg, V, mx, inv_t, priv_m, priv_c, &h0);
+    select_bin(h0.m, h0.c, 0ull, 0, ~0ull, sc_m, sc_c, &sel_sh, &sh_p);       // target = +inf: everything fits
+    Prefix all{0u, 0, sh_p.mass, sh_p.count};
     const unsigned long long Z = all.mass;
     Prefix kept = all;
     uint32_t keep_key = 0; int keep_tie = 0x7fffffff;
     if (top_p > 0.f && top_p < 1.f) {
       const unsigned long long tgt = (unsigned long long)((double)top_p * (double)Z);
-      kept = find_prefix(lg, V, mx, inv_t, tgt, hist_m, hist_c, &sh_p);
+      kept = find_prefix(lg, V, mx, inv_t, tgt, hist_m, hist_c, &sh_p, &h0, sc_m, sc_c, &sel_sh);
       keep_key = kept.kstar; keep_tie = kept.ntie;
       if (kept.count == 0) {  // top token alone exceeds top_p (reference: 0/0); keep top-1
         kept.count = 1; kept.mass = mass_fx(mx, mx, inv_t);
@@ -286,7 +427,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
     // first candidate whose inclusive cumulative mass exceeds u * Z_kept
     unsigned long long y = (unsigned long long)((double)u * (double)kept.mass);
     if (y >= kept.mass) y = kept.mass - 1;
-    Prefix pk = find_prefix(lg, V, mx, inv_t, y, hist_m, hist_c, &sh_p);
+    Prefix pk = find_prefix(lg, V, mx, inv_t, y, hist_m, hist_c, &sh_p, &h0, sc_m, sc_c, &sel_sh);
     // pk.count candidates lie strictly before the pick; the pick is the next one in order
     int rank_in_key = pk.ntie;
     uint32_t key = pk.kstar;
@@ -294,7 +435,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
       key = keep_key; rank_in_key = max(keep_tie - 1, 0);
       if (keep_tie == 0x7fffffff) { key = pk.kstar; rank_in_key = max(pk.ntie - 1, 0); }
     }
-    token = nth_tie(lg, V, key, rank_in_key, sh_i);
+    token = nth_tie(lg, V, key, rank_in_key, sh_i, tie_tbl, &sel_sh);
     if (token < 0 || token >= V) token = a.i;
   }
   // logprobs are reported as (lg - mx) * lp_scale - lp_lse: the plain log-softmax, or the one of logits / T
@@ -302,7 +443,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   if (c.lp_temp && temperature > 0.f) {
     lp_scale = 1.0f / temperature;
     float st = 0.f;
-    for (int i = threadIdx.x; i < V; i += ST) st += __expf((lg[i] - mx) * lp_scale);
+    for_row(lg, V, [&](float l, int) { st += __expf((l - mx) * lp_scale); });
     st = block_sum(st, sh_f);
     lp_lse = __logf(st);
   }
@@ -315,10 +456,9 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
     float prev_v = INFINITY; int prev_i = -1;
     for (int r = 0; r < c.top_logprobs; ++r) {
       ArgMax t{-INFINITY, 0x7fffffff};
-      for (int i = threadIdx.x; i < V; i += ST) {
-        const float v = lg[i];
+      for_row(lg, V, [&](float v, int i) {
         if (v < prev_v || (v == prev_v && i > prev_i)) t = am_better(t, ArgMax{v, i});
-      }
+      });
       t = block_argmax(t, sh_am);
       if (threadIdx.x == 0) {
         c.topk_ids[(size_t)b * c.top_logprobs + r] = t.i;
