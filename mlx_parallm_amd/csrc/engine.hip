@@ -82,6 +82,7 @@ struct mi_engine {
   int32_t* d_tokens = nullptr; size_t d_tokens_cap = 0;
   int32_t* d_forced = nullptr; size_t d_forced_cap = 0;   // mi_score_tokens targets
   float* d_rowpar = nullptr; size_t d_rowpar_cap = 0;     // per-row temperature | top_p of the current step
+  void* deq_scratch = nullptr; size_t deq_cap = 0;        // [hi | lo] 16-bit copy of one int4 matrix (prefill GEMM)
   int32_t* d_next = nullptr;      // tokens sampled by the last step [maxB]
   float* d_logprob = nullptr; float* d_prob0 = nullptr; float* d_rowstats = nullptr; float* d_uniforms = nullptr;
   int32_t* d_topk_ids = nullptr; float* d_topk_lp = nullptr;
@@ -295,7 +296,19 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
-    return launch_gemm_prefill(f.W, c, rows, e->stream);
+    void* scratch = nullptr;
+    if (wk_is_quant(f.W.wk)) {               // int4: the GEMM multiplies by a [hi | lo] 16-bit copy made on the fly
+      const size_t need = dequant_hilo_bytes(f.W.N, f.W.K);
+      if (need > e->deq_cap) {
+        MI_HIP(hipStreamSynchronize(e->stream));
+        hipFree(e->deq_scratch);
+        e->deq_scratch = nullptr; e->deq_cap = 0;
+        MI_HIP(hipMalloc(&e->deq_scratch, need));
+        e->deq_cap = need;
+      }
+      scratch = e->deq_scratch;
+    }
+    return launch_gemm_prefill(f.W, c, rows, e->stream, scratch);
   }
   const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
   GemvCall probe = c; probe.M = (int)std::min<size_t>(rows, 16);
@@ -612,7 +625,7 @@ void mi_engine_destroy(mi_engine* e) {
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
-  hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar);
+  hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {

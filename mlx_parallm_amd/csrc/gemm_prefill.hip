@@ -41,7 +41,8 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 
 struct GemmParams {
   const void* x; int ldx; int M;
-  const void* w; int N, K;          // W tile-major; N = rows of W (SWIGLU: gate rows = N/2)
+  const void* w; int N, K;          // W tile-major; N = rows of W (SWIGLU: gate rows = N/2); K = its reduction length
+  int ka;                           // reduction length of x: K, or K/2 when W is a [hi | lo] pair (x is walked twice)
   int epi; void* out; int ldo; void* resid; int pair_offset;
 };
 
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
       const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
       const int gm = m0 + row;
       areg[i] = u32x4{0u, 0u, 0u, 0u};
-      if (gm < p.M) areg[i] = *(const u32x4*)(x + (size_t)gm * p.ldx + ks * BK + kq * 8);
+      if (gm < p.M) areg[i] = *(const u32x4*)(x + (size_t)gm * p.ldx + (ks * BK) % p.ka + kq * 8);
     }
   };
   auto store_a = [&](int buf) {
@@ -206,7 +207,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const AT* x, int ldx,
 bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
   if (rows < 32) return false;
-  if (!((W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16))) return false;
+  const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
+  const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
+                  W.K % 128 == 0;                       // through a [hi | lo] 16-bit copy (launch_dequant_q4_hilo)
+  if (!dense && !q4) return false;
   if (W.K % BK != 0 || c.ldx % 8 != 0) return false;
   if (c.epi == EPI_STORE_F32) return false;
   if (W.lora_b[0] != nullptr || W.lora_b[1] != nullptr) return false;
@@ -227,11 +231,17 @@ int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ld
   return MI_OK;
 }
 
-// c.pro must be PRO_NONE here (the caller runs launch_rmsnorm_rows first); rows = total rows of x
-int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st) {
+// c.pro must be PRO_NONE here (the caller runs launch_rmsnorm_rows first); rows = total rows of x.
+// int4 weights: `scratch` (>= dequant_hilo_bytes(N, K)) receives the [hi | lo] copy first.
+int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch) {
   if (c.pro != PRO_NONE) return fail(MI_ERR_INVALID, "gemm_prefill: normalise the rows first");
   GemmParams p{};
-  p.x = c.x; p.ldx = c.ldx; p.M = (int)rows; p.w = W.w; p.N = W.N; p.K = W.K;
+  p.x = c.x; p.ldx = c.ldx; p.M = (int)rows; p.w = W.w; p.N = W.N; p.K = W.K; p.ka = W.K;
+  if (wk_is_quant(W.wk)) {
+    if (scratch == nullptr) return fail(MI_ERR_INVALID, "gemm_prefill: int4 weights need a dequantisation scratch buffer");
+    MI_TRY(launch_dequant_q4_hilo(W, scratch, st));
+    p.w = scratch; p.K = 2 * W.K;
+  }
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
   const bool sw = c.epi == EPI_SWIGLU;
   const int ncols = sw ? c.pair_offset : W.N;

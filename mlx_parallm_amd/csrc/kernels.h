@@ -67,7 +67,10 @@ int gemv_pair_grid();
 
 // prefill (many rows): MFMA tile GEMM + row-wise RMSNorm (gemm_prefill.hip)
 bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows);
-int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st);
+int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch = nullptr);
+// int4 (tile-major) -> 16-bit tile-major [hi | lo], K' = 2K: the operand of the prefill GEMM for quantised weights
+size_t dequant_hilo_bytes(int N, int K);
+int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st);
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
                         hipStream_t st);
 

@@ -50,7 +50,51 @@ __global__ void repack_q4_kernel(const uint32_t* codes, const uint16_t* scales, 
   }
 }
 
+// int4 tile-major -> dense 16-bit tile-major [hi | lo] with K' = 2K (the prefill GEMM's operand for quantised
+// weights): w = scale * q + bias in float32 (as the oracle dequantises), hi = T(w), lo = T(w - hi), so that
+// x . hi + x . lo reproduces x . w to 2^-17 relative -- below the accumulation-order noise of any fp32 GEMM.
+// One thread per destination 16-byte piece of the hi half (coalesced writes; the codes are read once).
+template <typename T>
+__global__ void dequant_q4_hilo_kernel(const uint8_t* src, T* dst, int N, int K) {
+  const size_t pieces = (size_t)N * (K / 8);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pieces; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = idx >> 6;
+    const int lane = (int)(idx & 63), r = lane & 15, g = lane >> 4;
+    const size_t i = blk / (K / 32), j = blk % (K / 32);
+    const size_t row = i * 16 + r;
+    const int k = (int)j * 32 + g * 8;
+    const uint8_t* qb = src + tiled_block_q4(row, k, K);
+    const uint32_t codes = *(const uint32_t*)(qb + tiled_q4_code_off(row, k));
+    const float s = (float)*(const T*)(qb + tiled_q4_scale_off(row, k));
+    const float b = (float)*(const T*)(qb + tiled_q4_scale_off(row, k) + 64);
+    T hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = mul_add_unfused(s, (float)((codes >> (4 * e)) & 15u), b);
+      hi[e] = (T)w;
+      lo[e] = (T)(w - (float)hi[e]);
+    }
+    const size_t kb2 = (size_t)(2 * K) / 32;                       // 32-k blocks per row tile in the destination
+    T* dh = dst + ((i * kb2 + j) * 64 + lane) * 8;
+    T* dl = dst + ((i * kb2 + (size_t)(K / 32) + j) * 64 + lane) * 8;
+    *(u32x4*)dh = *(const u32x4*)hi;
+    *(u32x4*)dl = *(const u32x4*)lo;
+  }
+}
+
 }  // namespace
+
+size_t dequant_hilo_bytes(int N, int K) { return (size_t)N * K * 2 * 2; }
+
+int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st) {
+  if (src.layout != 1 || (src.wk != WK_Q4_BF16 && src.wk != WK_Q4_F16) || src.group != 64 || src.K % 128 != 0 || src.N % 16 != 0)
+    return fail(MI_ERR_UNSUPPORTED, "dequant: tile-major int4 (group 64) matrices only");
+  const dim3 grid(4096), block(256);
+  if (src.wk == WK_Q4_BF16) hipLaunchKernelGGL(dequant_q4_hilo_kernel<bf16>, grid, block, 0, st, (const uint8_t*)src.w, (bf16*)dst, src.N, src.K);
+  else hipLaunchKernelGGL(dequant_q4_hilo_kernel<f16>, grid, block, 0, st, (const uint8_t*)src.w, (f16*)dst, src.N, src.K);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
 
 bool tiled_supported(int wk, int N, int K, int group) {
   if (N % 16 != 0) return false;
