@@ -93,7 +93,7 @@ int launch_j(const MfmaParams& p, hipStream_t st) {
 
 template <typename AT, bool Q4, int MB, bool SWIGLU, int NW>
 int launch_one(const MfmaParams& p, hipStream_t st) {
-  if constexpr (!Q4 && MB == 8) {
+  if constexpr (MB == 8) {
     if (phase_nbuf(p.K, p.kc, MB, Q4) == 2)      // K spans several activation chunks: the double-buffered instantiation
       return p.kc <= 8 * NW * 64 ? launch_j<AT, Q4, MB, SWIGLU, NW, 1, true>(p, st) : launch_j<AT, Q4, MB, SWIGLU, NW, 2, true>(p, st);
   }

@@ -63,10 +63,18 @@ __device__ __forceinline__ u32x4 unpack_q4(uint32_t v) {
   // fragment element 2p <- nibble p, element 2p+1 <- nibble p+4
   u32x4 r;
   if constexpr (std::is_same<T, bf16>::value) {
-    r.x = ((v << 3) & 0x00780078u) | 0x41804180u;
-    r.y = ((v >> 1) & 0x00780078u) | 0x41804180u;
-    r.z = ((v >> 5) & 0x00780078u) | 0x41804180u;
-    r.w = ((v >> 9) & 0x00780078u) | 0x41804180u;
+    // (x & mask) | magic as ONE v_and_or_b32 with both constants in registers: hipcc emits v_and + v_or with
+    // literals (a VOP3 cannot carry two), and this kernel is bound by its VALU instruction count
+    const uint32_t mask = 0x00780078u, magic = 0x41804180u;
+    auto and_or = [&](uint32_t x) {
+      uint32_t o;
+      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(mask), "v"(magic));
+      return o;
+    };
+    r.x = and_or(v << 3);
+    r.y = and_or(v >> 1);
+    r.z = and_or(v >> 5);
+    r.w = and_or(v >> 9);
   } else {
     const f16x2 off = {(_Float16)1024.f, (_Float16)1024.f};
     r.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, (v & 0x000F000Fu) | 0x64006400u) - off);
@@ -119,8 +127,7 @@ __host__ __device__ constexpr size_t phase_lds_bytes(int kc, int MB, int nbuf) {
   return nbuf * ((size_t)kc * MB * 2 + (Q4 ? (size_t)(kc / 64) * MB * 4 : 0)) + (size_t)NW * NA * 64 * 4 * 4 + 16 * 4 +
          (size_t)NW * 16 * 4;
 }
-// (dense weights only: the int4 variants have no registers to spare for the in-loop staging pass)
-__host__ __device__ constexpr int phase_nbuf(int K, int kc, int MB, bool q4) { return (K > kc && MB == 8 && !q4) ? 2 : 1; }
+__host__ __device__ constexpr int phase_nbuf(int K, int kc, int MB, bool q4) { (void)q4; return (K > kc && MB == 8) ? 2 : 1; }
 
 // One GEMV.  Work is cut into "batches": TB 16-row tiles x a KS-wide slice of K (KS = NW * UK * BK:
 // every wave issues UK 16-byte loads per tile per batch, ALL of them before it touches the
@@ -287,14 +294,15 @@ struct Phase {
   // ---- MFMAs of slot u of batch [k0, k0+KS) clipped to kend; fragments are addressed relative to cbase
   __device__ __forceinline__ void mfma_u(int u, int k0, int kend, int cbase) {
     const int kq = k0 + (u * NW + wave) * BK;
-    const bool valid = kq < kend;                     // wave-uniform; an invalid slot multiplies zeros
-    const int kb = valid ? (kq - cbase) / BK : 0;
-    const bool lane_on = valid && (MB == 16 || c16 < MB);
+    // A slot past kend holds clamped (valid but meaningless) weights: it is skipped (wave-uniform branch; no global
+    // load inside).  With MB = 8 the fragment rows 8..15 are the rows 0..7 again (cm = c16 & 7): output rows 8..15
+    // come out as copies and are never stored (finish: m < p.M), so no lane is masked -- the selects that zeroed
+    // them were a sixth of the int4 kernel's VALU instructions (SQ_INSTS_VALU), and that kernel is VALU-bound.
+    if (kq >= kend) return;
+    const int kb = (kq - cbase) / BK;
     const int cm = c16 & (MB - 1);
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     if constexpr (!Q4) {
-      u32x4 af = frag[(kb * 4 + g) * MB + cm];
-      af = lane_on ? af : zero4;
+      const u32x4 af = frag[(kb * 4 + g) * MB + cm];
 #pragma unroll
       for (int t = 0; t < TB; ++t)
 #pragma unroll
@@ -307,10 +315,8 @@ struct Phase {
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
           af[s][t2] = frag[((((kb * 2 + s) * 2 + t2) * 4 + g) * MB + cm)];
-          af[s][t2] = lane_on ? af[s][t2] : zero4;
         }
         sxv[s] = *(const f32x4*)&sx[(kb * 2 + s) * MB + ((g * 4) & (MB - 1))];
-        if (!(valid && (MB == 16 || g * 4 < MB))) sxv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int t = 0; t < TB; ++t)
