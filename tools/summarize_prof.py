@@ -54,11 +54,12 @@ def pretty(name: str) -> str:
         return {"gemm_tile_kernel": "gemm_tile_kernel<bf16,swiglu>"}.get(base, base + "<bf16,...>")
     n = name.replace("void ", "").replace("mi::(anonymous namespace)::", "").replace("mi::", "")
     n = re.sub(r"\(.*\)$", "", n).replace(" [clone .kd]", "").replace(".kd", "")
-    m = re.match(r"gemv_mfma_kernel<(\w+), (true|false), (\d+), (true|false)(?:, (\d+))?(?:, (\d+))?>", n)
+    m = re.match(r"gemv_mfma_kernel<(\w+), (true|false), (\d+), (true|false)(?:, (\d+))?(?:, (\d+))?(?:, (true|false))?>", n)
     if m:
         at = {"__bf16": "bf16", "_Float16": "f16"}.get(m.group(1), m.group(1))
-        return "gemv_mfma_kernel<%s,%s,MB=%s,%s>" % (at, "int4" if m.group(2) == "true" else "dense", m.group(3),
-                                                      "swiglu" if m.group(4) == "true" else "plain")
+        return "gemv_mfma_kernel<%s,%s,MB=%s,%s%s>" % (at, "int4" if m.group(2) == "true" else "dense", m.group(3),
+                                                        "swiglu" if m.group(4) == "true" else "plain",
+                                                        ",dbuf" if m.group(7) == "true" else "")
     m = re.match(r"gemm_tile_kernel<(\w+), (true|false)>", n)
     if m:
         at = {"__bf16": "bf16", "_Float16": "f16"}.get(m.group(1), m.group(1))
