@@ -45,6 +45,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="Disable prompt de-duplication and prefix sharing.")
     p.add_argument("--max-context-length", type=int, default=d.max_context_length)
     p.add_argument("--device", type=int, default=d.device, help="HIP device index.")
+    p.add_argument("--devices", default=None, help="Comma-separated HIP device indices: one model replica per GPU, "
+                   "requests spread over them (implies --scheduler continuous).")
     p.add_argument("--version", action="version", version="0.1.0")
     return p
 
@@ -55,7 +57,8 @@ def parse_args(argv: Optional[Sequence[str]] = None) -> ServerConfig:
                         max_batch_size=ns.max_batch_size, batch_timeout=ns.batch_timeout,
                         request_timeout_seconds=ns.request_timeout_seconds,
                         max_concurrent_streams=ns.max_concurrent_streams, scheduler=ns.scheduler,
-                        diverse_mode=bool(ns.diverse_mode), max_context_length=ns.max_context_length, device=ns.device)
+                        diverse_mode=bool(ns.diverse_mode), max_context_length=ns.max_context_length, device=ns.device,
+                        devices=[int(x) for x in ns.devices.split(",")] if ns.devices else None)
 
 
 def cli_runner(argv: Optional[Sequence[str]] = None) -> None:

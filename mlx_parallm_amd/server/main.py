@@ -88,6 +88,7 @@ class ServerConfig:
     max_context_length: int = 32768
     stream_batch_timeout: float = 0.02            # main.py:85
     device: int = 0
+    devices: Optional[List[int]] = None           # more than one: a model replica per GPU (continuous scheduler)
 
     @classmethod
     def from_env(cls, base: Optional["ServerConfig"] = None) -> "ServerConfig":
@@ -195,7 +196,8 @@ class ServerState:
         self.stream_slots = asyncio.Semaphore(max(1, config.max_concurrent_streams))
         self.tasks: List[asyncio.Task] = []
         self.model_id: Optional[str] = None
-        self.scheduler = None              # ContinuousScheduler when config.scheduler == "continuous"
+        self.scheduler = None              # ReplicaPool of ContinuousSchedulers when config.scheduler == "continuous"
+        self.extra_replicas: List[Any] = []   # models on the 2nd .. nth device (config.devices)
 
 
 # ------------------------------------------------------------------------------------------
@@ -706,7 +708,8 @@ def _load_initial_model(state: ServerState) -> None:
     state.model_id = rec.id
     try:
         try:
-            model, tokenizer = load(cfg.model_path, adapter_path=cfg.lora_path, device=cfg.device)
+            model, tokenizer = load(cfg.model_path, adapter_path=cfg.lora_path,
+                                    device=(cfg.devices[0] if cfg.devices else cfg.device))
         except TypeError:
             model, tokenizer = load(cfg.model_path, adapter_path=cfg.lora_path)
         rec.model_instance, rec.tokenizer_instance, rec.status = model, tokenizer, ModelStatus.LOADED
@@ -752,13 +755,24 @@ def create_app(config: Optional[ServerConfig] = None, *, model=None, tokenizer=N
         if config.scheduler not in ("default", "continuous"):
             log.warning("unknown scheduler %r; using 'default'", config.scheduler)
         rec = _loaded(state.model_id)
+        if rec is not None and model is None and config.devices and len(config.devices) > 1:
+            # one replica per further GPU (the first device already holds the registry's model); sequences are
+            # spread over the replicas by the continuous scheduler, so that mode is implied
+            from ..utils import load
+
+            def more():
+                return [load(config.model_path, adapter_path=config.lora_path, device=d)[0] for d in config.devices[1:]]
+            state.extra_replicas = await asyncio.get_running_loop().run_in_executor(None, more)
+            if config.scheduler != "continuous":
+                log.info("%d devices: using the continuous scheduler", len(config.devices))
+                config.scheduler = "continuous"
         if config.scheduler == "continuous" and rec is not None:
             # admit-on-step over the engine's row-subset steps (server/scheduler.py); every generation route
             # goes through it, the windowed workers are not started
-            from .scheduler import ContinuousScheduler
+            from .scheduler import ReplicaPool
 
-            state.scheduler = ContinuousScheduler(rec.model_instance, rec.tokenizer_instance,
-                                                  max_slots=config.max_batch_size, metrics=state.metrics)
+            state.scheduler = ReplicaPool([rec.model_instance] + state.extra_replicas, rec.tokenizer_instance,
+                                          max_slots=config.max_batch_size, metrics=state.metrics)
             state.scheduler.start()
             state.tasks = []
         else:

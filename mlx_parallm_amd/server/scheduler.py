@@ -273,3 +273,38 @@ class ContinuousScheduler:
             if not s.finished:
                 s.finished = "error"
                 self._emit(s, None, "error")
+
+
+class ReplicaPool:
+    """One ContinuousScheduler per model replica (one replica per GPU, SURVEY §8e: sequences are independent, every
+    GPU holds the full weights and its own KV rows, nothing crosses GPUs during decode).  A new sequence goes to
+    the replica with the fewest sequences in flight; each replica steps on its own host thread."""
+
+    def __init__(self, models, tokenizer, max_slots: int = 8, metrics=None, **kw):
+        self.replicas: List[ContinuousScheduler] = [ContinuousScheduler(m, tokenizer, max_slots=max_slots, metrics=metrics, **kw)
+                                                    for m in models]
+        self._lock = threading.Lock()
+
+    def _load(self, r: ContinuousScheduler) -> int:
+        return len(r.pending) + sum(1 for s in r.slots if s is not None and not s.finished)
+
+    def submit(self, prompt_ids, max_tokens: int, temp: float, top_p: float, sink: Sink) -> Sequence:
+        with self._lock:                      # (choice and enqueue together, so concurrent submits spread out)
+            r = min(self.replicas, key=self._load)
+            return r.submit(prompt_ids, max_tokens, temp, top_p, sink)
+
+    def start(self) -> None:
+        for r in self.replicas:
+            r.start()
+
+    def stop(self) -> None:
+        for r in self.replicas:
+            r.stop()
+
+    def borrow_engine(self):
+        """Exclusive use of replica 0's engine (the model object the registry exposes)."""
+        return self.replicas[0].borrow_engine()
+
+    @property
+    def max_rows_seen(self) -> int:
+        return max(r.max_rows_seen for r in self.replicas)

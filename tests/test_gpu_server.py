@@ -26,7 +26,7 @@ def _free_port() -> int:
         return int(s.getsockname()[1])
 
 
-@pytest.fixture(scope="module", params=["default", "continuous"])
+@pytest.fixture(scope="module", params=["default", "continuous", "replicas"])   # replicas: two model copies ("--devices 0,0")
 def server(request, tiny_dirs, tmp_path_factory):
     model_dir = tiny_dirs["llama_q4_f32"][0]
     port = _free_port()
@@ -34,7 +34,8 @@ def server(request, tiny_dirs, tmp_path_factory):
     env = os.environ.copy()
     env["PYTHONPATH"] = str(ROOT) + os.pathsep + env.get("PYTHONPATH", "")
     args = [sys.executable, "-m", "mlx_parallm_amd.cli", "--model-path", model_dir, "--host", "127.0.0.1", "--port", str(port),
-            "--max-batch-size", "8", "--batch-timeout", "0.2", "--diverse-mode", "false", "--scheduler", request.param]
+            "--max-batch-size", "8", "--batch-timeout", "0.2", "--diverse-mode", "false"]
+    args += ["--devices", "0,0", "--max-batch-size", "4"] if request.param == "replicas" else ["--scheduler", request.param]
     with open(log_path, "w", buffering=1) as lf:
         proc = subprocess.Popen(args, cwd=str(ROOT), stdout=lf, stderr=subprocess.STDOUT, text=True, env=env)
     base = f"http://127.0.0.1:{port}"

@@ -114,6 +114,35 @@ def test_per_row_sampling_parameters(tiny, parts):
     assert done["greedy"] == want and done["hot"] != want
 
 
+def test_replica_pool_spreads_sequences_over_replicas(tiny, parts):
+    """One scheduler per model replica (one per GPU in production); new sequences go to the least loaded."""
+    from mlx_parallm_amd.server.scheduler import ReplicaPool
+
+    model, tok = parts
+    other = FakeModel(tiny, max_pos=2048)
+    pool = ReplicaPool([model, other], tok, max_slots=2)
+    pool.start()
+    done, ev = {}, threading.Event()
+
+    def sink(i):
+        def f(seq, delta, reason):
+            if reason is not None:
+                done[i] = list(seq.generated)
+                if len(done) == 4:
+                    ev.set()
+        return f
+
+    prompts = [tok.encode(f"prompt number {i}") for i in range(4)]
+    for i, p in enumerate(prompts):
+        pool.submit(p, 6, 0.0, 1.0, sink(i))
+    assert ev.wait(timeout=120)
+    pool.stop()
+    for i, p in enumerate(prompts):
+        assert done[i] == _alone(tiny, p, 6, tok.eos_token_id)[0]
+    used = [sum(1 for e in m.engine.trace if e[0] == "reset_row") for m in (model, other)]
+    assert used == [2, 2]                                  # two sequences each
+
+
 async def _serving(parts, **cfg):
     config = srv.ServerConfig(model_path=MODEL_ID, scheduler="continuous", **cfg)
     app = srv.create_app(config, model=parts[0], tokenizer=parts[1], model_id=MODEL_ID)
