@@ -15,6 +15,7 @@
 //     The next step's 8 fragments are prefetched into a second register set.
 //   * SwiGLU: a wave's four N tiles are two gate tiles and the two matching up tiles, so
 //     silu(gate) * up happens in registers.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -172,6 +173,135 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 in M x 4 in N, 128 x 64 per wave = 8 x 4 MFMA tiles), BOTH operands staged in
+// LDS.  Why: with W fragments read per wave from global memory the 128 x 128 kernel moves 48 KB from L2 per
+// 2.1 MFLOP (44 flop/B) and sits on the L2 -> CU bandwidth (~19 TB/s at its 840 TFLOP/s); here a K step moves
+// 64 KB per 8.4 MFLOP (131 flop/B).  The W block of a K step keeps its tile-major order in LDS -- a fragment is one
+// contiguous KiB, read conflict-free -- so the copy global -> registers -> LDS is a plain 16-byte lane-linear move.
+// Double-buffered: the next step's 8 loads per thread are in flight during the current step's 64 MFMAs per wave.
+// SWIGLU: the block covers 128 gate columns and the 128 matching up columns; a wave's four N tiles are two gate
+// tiles + their up tiles.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int A2_BYTES = BM2 * LDA * 2;                 // one X image (rows padded to 144 B)
+constexpr int B2_BYTES = BN2 * BK * 2;                  // one W image: 16 row tiles x 2 k blocks x 1 KiB
+constexpr int LDS2_BYTES = 2 * (A2_BYTES + B2_BYTES);
+
+template <typename AT, bool SWIGLU>
+__global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;              // 2 x 4 waves
+  const int c16 = lane & 15, g = lane >> 4;
+  const int bm = blockIdx.x, bn = blockIdx.y;           // M fastest: co-scheduled blocks share the W tiles in L2
+  const int m0 = bm * BM2;
+  const int nk = p.K / BK;
+  const AT* x = (const AT*)p.x;
+  const int ntiles_w = p.N / 16;
+  auto a_img = [&](int buf) { return (AT*)(smem2 + (size_t)buf * A2_BYTES); };
+  auto b_img = [&](int buf) { return smem2 + 2 * (size_t)A2_BYTES + (size_t)buf * B2_BYTES; };
+
+  // the 16 W row tiles of this block, in LDS order: tile slot s (0..15)
+  auto w_tile_of = [&](int s) -> int {
+    int t;
+    if constexpr (!SWIGLU) t = (bn * BN2) / 16 + s;
+    else t = (bn * 128 + (s >> 2) * 32 + (s & 1) * 16 + ((s >> 1) & 1) * p.pair_offset) / 16;   // wave wn = s>>2: gate, gate, up, up
+    return min(t, ntiles_w - 1);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- global -> registers: X 256 rows x 8 chunks = 2048 pieces, W 16 tiles x 2 k blocks x 64 lanes = 2048 pieces
+  u32x4 areg[4], breg[4];
+  auto load_ab = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
+      const int gm = m0 + row;
+      areg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (gm < p.M) areg[i] = *(const u32x4*)(x + (size_t)gm * p.ldx + (ks * BK) % p.ka + kq * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i, s = c >> 7, kb = (c >> 6) & 1, l = c & 63;
+      const char* blk = (const char*)p.w + ((size_t)w_tile_of(s) * (p.K / 32) + (size_t)(ks * 2 + kb)) * 1024;
+      breg[i] = *(const u32x4*)(blk + l * 16);
+    }
+  };
+  auto store_ab = [&](int buf) {
+    AT* A = a_img(buf);
+    unsigned char* B = b_img(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
+      *(u32x4*)&A[row * LDA + kq * 8] = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(B + (size_t)(tid + 512 * i) * 16) = breg[i];     // (slot, kb, lane) order = piece index
+  };
+
+  load_ab(0);
+  store_ab(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) load_ab(ks + 1);
+    const AT* A = a_img(cur);
+    const unsigned char* B = b_img(cur);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      u32x4 bf[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bf[nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + kb) * 64 + lane) * 16);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const u32x4 af = *(const u32x4*)&A[(wm * 128 + mt * 16 + c16) * LDA + kb * 32 + g * 8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<AT>(af, bf[nt], acc[mt][nt]);
+      }
+    }
+    if (ks + 1 < nk) store_ab(cur ^ 1);          // the other buffer: its readers finished before the last barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (c16, g) holds C[m = 4g + r][n = c16] of every 16 x 16 tile
+  AT* out = (AT*)p.out;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 128 + mt * 16 + 4 * g + r;
+      if (m >= p.M) continue;
+      if constexpr (SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = bn * 128 + wn * 32 + j * 16 + c16;
+          if (n >= p.pair_offset) continue;
+          const float gt = (float)(AT)acc[mt][j][r], up = (float)(AT)acc[mt][j + 2][r];
+          const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+          const float sl = (float)(AT)(gt * sig);
+          out[(size_t)m * p.ldo + n] = (AT)(sl * up);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = bn * BN2 + wn * 64 + nt * 16 + c16;
+          if (n >= p.N) continue;
+          const float y = (float)(AT)acc[mt][nt][r];
+          if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
+          else {
+            AT* h = (AT*)p.resid;
+            h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+          }
+        }
+      }
+    }
+}
+
 // out[row][:] = w * cast_T(x32 * rsqrt(mean(x32^2) + eps))   (nn.RMSNorm); one wave per row
 template <typename AT>
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const AT* x, int ldx, const AT* w, AT* out, int ldo,
@@ -245,6 +375,19 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
   const bool sw = c.epi == EPI_SWIGLU;
   const int ncols = sw ? c.pair_offset : W.N;
+  static const bool small_only = getenv("MI_GEMM_TILE128") != nullptr;        // A/B: always the 128 x 128 kernel
+  if (rows >= 256 && !small_only) {                      // both operands through LDS (gemm_tile256_kernel)
+    const int bn = sw ? 128 : BN2;
+    const dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
+#define GO256(T, S) do { auto k = gemm_tile256_kernel<T, S>; \
+      MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
+      hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } while (0)
+    if (c.act == MI_BF16) { if (sw) GO256(bf16, true); else GO256(bf16, false); }
+    else { if (sw) GO256(f16, true); else GO256(f16, false); }
+#undef GO256
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   const dim3 grid(((int)rows + BM - 1) / BM, (ncols + (sw ? 64 : BN) - 1) / (sw ? 64 : BN)), block(256);
   if (c.act == MI_BF16) {
     if (sw) hipLaunchKernelGGL((gemm_tile_kernel<bf16, true>), grid, block, 0, st, p);

@@ -186,19 +186,20 @@ def test_paired_gemv_launches_are_bit_identical(tiny_dirs, name):
     model.engine.close()
 
 
+@pytest.mark.parametrize("L0", [43, 75])       # 172 rows: the 128 x 128 kernel; 300 rows: the 256 x 256 LDS-staged kernel
 @pytest.mark.parametrize("name", ["llama_bf16_gqa", "qwen3_bf16", "llama_q4_bf16"])
-def test_prefill_tile_gemm_matches_oracle_and_chunked_path(tiny_dirs, name):
+def test_prefill_tile_gemm_matches_oracle_and_chunked_path(tiny_dirs, name, L0):
     """Prefill with enough rows (B*L = 172, not a multiple of the 128-row tile) to take the MFMA tile
     GEMM (gemm_prefill.hip): all-position logits against the oracle and against the chunked
     skinny-kernel path, then decode on top of the KV it wrote.  int4 weights go through the [hi | lo]
     dequantised copy (2^-17 relative), which must be indistinguishable at this tolerance."""
     model, ref, cfg = _load_pair(tiny_dirs, name)
-    B, L0 = 4, 43
+    B = 4
     toks = _left_pad_prompts(cfg, B, L0)
     outs = []
     for gemm in (1, 0):
         model.engine.set_option("prefill_gemm", gemm)
-        kv = model.engine.new_kv(B, capacity=64, kv_dtype="model")
+        kv = model.engine.new_kv(B, capacity=96, kv_dtype="model")
         pre = model.engine.forward(toks, kv, all_positions=True)
         nxt = model.engine.forward(toks[:, -1:], kv)
         outs.append((pre, nxt))
