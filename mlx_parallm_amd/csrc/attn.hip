@@ -267,241 +267,6 @@ int launch_attn_d(const AttnCall& c, hipStream_t st) {
   return fail(MI_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
 }
 
-#if 0  // first version of the fused decode kernel; superseded by attn_decode.hip
-// ------------------------------------------------------------------------------------------
-// Fused decode step of one attention block (L == 1): q/k RMSNorm (qwen3) + RoPE + KV append +
-// split-KV attention + split combine in ONE launch.  Grid (nsplit, B*Hkv), 512 threads.
-//   * every lane group of 16 lanes owns D/16 elements; the RoPE partner (i <-> i + D/2) is the
-//     lane 8 positions away, the per-head norm is a 16-lane reduction -- no LDS needed;
-//   * the split that contains the new position appends K/V and takes the new key from
-//     registers (never re-reads its own store);
-//   * each (wave, lane group) issues up to U K-rows and U V-rows before it touches any of them:
-//     with 8 waves a 256-key split is entirely in flight at once;
-//   * splits publish (max, sum, O) partials and take a ticket; the last arriver of a
-//     (sequence, kv-head) combines them (agent-scope release / acquire, bounded by construction:
-//     nobody waits, the last one simply finds the others' data).
-template <typename T, int D, int G>
-__global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
-  constexpr int EPL = D / 16, NWV = 8, U = 8;
-  const AttnShape& s = c.s;
-  const int split = blockIdx.x, bh = blockIdx.y;
-  const int b = bh / s.Hkv, kh = bh % s.Hkv;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, gq = lane >> 4;
-  const int pos = c.offsets[b];
-  const int n_keys = pos + 1;
-  const int chunk = (n_keys + c.nsplit - 1) / c.nsplit;
-  const int s0 = split * chunk, s1 = min(n_keys, s0 + chunk);
-  const bool owner = pos >= s0 && pos < s1;
-  const int nq = s.Hq * D;
-  const T* row = (const T*)c.qkv + (size_t)b * (nq + 2 * s.Hkv * D);
-
-  __shared__ float st_m[NWV][G], st_l[NWV][G];
-  __shared__ float st_o[NWV][G][D];
-  __shared__ int is_last_sh;
-
-  const bool hi = li >= 8;                       // this lane holds the second half of a RoPE pair
-  float cs[EPL], sn[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    const int i = (li & 7) * EPL + e;
-    cs[e] = c.cos_tab[(size_t)pos * (D / 2) + i];
-    sn[e] = c.sin_tab[(size_t)pos * (D / 2) + i];
-  }
-  auto norm_rope = [&](float (&x)[EPL], const T* nw) {
-    if (nw != nullptr) {
-      float ss = 0.f;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) ss = fmaf(x[e], x[e], ss);
-      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
-      const float rs = 1.0f / sqrtf(ss / (float)D + c.eps);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        x[e] = to_f32(store_act<T>(to_f32(store_act<T>(x[e] * rs, s.rnd)) * (float)nw[li * EPL + e], s.rnd));
-    }
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const float p = __shfl_xor(x[e], 8, 64);
-      const float o = hi ? (p * sn[e] + x[e] * cs[e]) : (x[e] * cs[e] - p * sn[e]);
-      x[e] = to_f32(store_act<T>(o, s.rnd));
-    }
-  };
-
-  float q[G][EPL];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    load_row_piece<T, EPL>(row + (size_t)(kh * G + g) * D + li * EPL, q[g]);
-    norm_rope(q[g], (const T*)c.q_norm_w);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) q[g][e] *= c.scale;
-  }
-  float kn[EPL], vn[EPL];
-  load_row_piece<T, EPL>(row + nq + (size_t)kh * D + li * EPL, kn);
-  load_row_piece<T, EPL>(row + nq + (size_t)(s.Hkv + kh) * D + li * EPL, vn);
-  norm_rope(kn, (const T*)c.k_norm_w);
-  T* kc = (T*)c.kcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
-  T* vc = (T*)c.vcache + ((size_t)b * s.Hkv + kh) * s.cap * D;
-  if (owner && wave == 0 && gq == 0 && pos < s.cap) {
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      kc[(size_t)pos * D + li * EPL + e] = (T)kn[e];
-      vc[(size_t)pos * D + li * EPL + e] = (T)vn[e];
-    }
-  }
-
-  float m[G], l[G], o[G][EPL];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    m[g] = -INFINITY; l[g] = 0.f;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
-  }
-  auto update = [&](const float (&kk)[EPL], const float (&vv)[EPL], bool ok) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) d = fmaf(q[g][e], kk[e], d);
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-      if (ok) {
-        const float mn = fmaxf(m[g], d);
-        const float corr = __expf(m[g] - mn);
-        const float pr = __expf(d - mn);
-        l[g] = l[g] * corr + pr;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) o[g][e] = fmaf(pr, vv[e], o[g][e] * corr);
-        m[g] = mn;
-      }
-    }
-  };
-
-  const int send = min(s1, pos);                 // cached keys of this split: [s0, send)
-  const T* kbase = kc + li * EPL;
-  const T* vbase = vc + li * EPL;
-  for (int sb = s0 + 4 * wave + gq; sb < send; sb += 4 * NWV * U) {
-    float kk[U][EPL], vv[U][EPL];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int sp = sb + 4 * NWV * u;
-      const int spc = sp < send ? sp : s0;
-      load_row_piece<T, EPL>(kbase + (size_t)spc * D, kk[u]);
-      load_row_piece<T, EPL>(vbase + (size_t)spc * D, vv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) update(kk[u], vv[u], sb + 4 * NWV * u < send);
-  }
-  // the new key, from registers (uniform branch per wave; inactive groups pass ok = false)
-  if (owner && wave == 0) update(kn, vn, gq == 0);
-
-  // ---- merge the four lane groups of the wave, then the waves
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const float mo = __shfl_xor(m[g], off, 64);
-      const float lo = __shfl_xor(l[g], off, 64);
-      const float mn = fmaxf(m[g], mo);
-      const float ca = (m[g] == -INFINITY) ? 0.f : __expf(m[g] - mn);
-      const float cb = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
-      l[g] = l[g] * ca + lo * cb;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        const float oo = __shfl_xor(o[g][e], off, 64);
-        o[g][e] = o[g][e] * ca + oo * cb;
-      }
-      m[g] = mn;
-    }
-    if (gq == 0) {
-      if (li == 0) { st_m[wave][g] = m[g]; st_l[wave][g] = l[g]; }
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) st_o[wave][g][li * EPL + e] = o[g][e];
-    }
-  }
-  __syncthreads();
-  T* out = (T*)c.out + (size_t)b * nq;
-  for (int idx = tid; idx < G * D; idx += 512) {
-    const int g = idx / D, d = idx % D;
-    float mn = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) mn = fmaxf(mn, st_m[w][g]);
-    float L = 0.f, O = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-      const float cw = (st_m[w][g] == -INFINITY) ? 0.f : __expf(st_m[w][g] - mn);
-      L = fmaf(st_l[w][g], cw, L);
-      O = fmaf(st_o[w][g][d], cw, O);
-    }
-    const int h = kh * G + g;
-    if (c.nsplit == 1) {
-      out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
-    } else {
-      float* pp = c.partial + (((size_t)b * s.Hq + h) * c.nsplit + split) * (D + 2);
-      pp[2 + d] = O;
-      if (d == 0) { pp[0] = mn; pp[1] = L; }
-    }
-  }
-  if (c.nsplit == 1) return;
-
-  // ---- publish, take a ticket; the last split of this (b, kv-head) combines
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(&c.counters[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = ticket == c.nsplit - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&c.counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    is_last_sh = last;
-  }
-  __syncthreads();
-  if (!is_last_sh) return;
-  for (int idx = tid; idx < G * D; idx += 512) {
-    const int g = idx / D, d = idx % D, h = kh * G + g;
-    const float* pp = c.partial + ((size_t)b * s.Hq + h) * c.nsplit * (D + 2);
-    float mn = -INFINITY;
-    for (int i = 0; i < c.nsplit; ++i) mn = fmaxf(mn, pp[i * (D + 2)]);
-    float L = 0.f, O = 0.f;
-    for (int i = 0; i < c.nsplit; ++i) {
-      const float mi_ = pp[i * (D + 2)];
-      const float cw = (mi_ == -INFINITY) ? 0.f : __expf(mi_ - mn);
-      L = fmaf(pp[i * (D + 2) + 1], cw, L);
-      O = fmaf(pp[i * (D + 2) + 2 + d], cw, O);
-    }
-    out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
-  }
-}
-
-template <typename T, int D>
-int launch_attn_decode_g(const AttnDecodeCall& c, hipStream_t st) {
-  const AttnShape& s = c.s;
-  const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
-  switch (s.Hq / s.Hkv) {
-    case 1: hipLaunchKernelGGL((attn_decode_kernel<T, D, 1>), grid, block, 0, st, c); break;
-    case 2: hipLaunchKernelGGL((attn_decode_kernel<T, D, 2>), grid, block, 0, st, c); break;
-    case 4: hipLaunchKernelGGL((attn_decode_kernel<T, D, 4>), grid, block, 0, st, c); break;
-    case 5: hipLaunchKernelGGL((attn_decode_kernel<T, D, 5>), grid, block, 0, st, c); break;
-    case 8: hipLaunchKernelGGL((attn_decode_kernel<T, D, 8>), grid, block, 0, st, c); break;
-    default: return fail(MI_ERR_UNSUPPORTED, "attention: Hq/Hkv must be 1, 2, 4, 5 or 8");
-  }
-  MI_HIP(hipGetLastError());
-  return MI_OK;
-}
-
-template <typename T>
-int launch_attn_decode_d(const AttnDecodeCall& c, hipStream_t st) {
-  switch (c.s.D) {
-    case 16: return launch_attn_decode_g<T, 16>(c, st);
-    case 32: return launch_attn_decode_g<T, 32>(c, st);
-    case 64: return launch_attn_decode_g<T, 64>(c, st);
-    case 128: return launch_attn_decode_g<T, 128>(c, st);
-  }
-  return fail(MI_ERR_UNSUPPORTED, "attention: head_dim must be 16, 32, 64 or 128");
-}
-#endif
 
 }  // namespace
 
