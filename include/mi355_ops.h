@@ -83,6 +83,11 @@ int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a);
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a);
 /* launches the same call `iters` times back to back and returns the mean launch time (HIP events) */
 int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
+/* the split-K weight-streaming GEMM the engine uses for 17..64 rows (decode steps of large batches), on its own:
+ * a->M in 17..64, a->pro = MI_PRO_NONE, tile-major 16-bit or int4 (group 64) weights.  ksplit 0 = the library's
+ * cost model (returned in *ksplit_used); iters >= 1 also times that many back-to-back launches into *avg_ms. */
+int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters,
+                      float* avg_ms);
 /* tile-major weight layout of the streaming kernels (what mi_engine_finalize applies to eligible
  * matrices): returns the size of the tiled buffer (0 if the matrix is not eligible) / fills `dst`. */
 uint64_t mi_op_tiled_bytes(const mi_op_linear* row_major);

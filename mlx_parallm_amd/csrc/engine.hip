@@ -83,6 +83,8 @@ struct mi_engine {
   int32_t* d_forced = nullptr; size_t d_forced_cap = 0;   // mi_score_tokens targets
   float* d_rowpar = nullptr; size_t d_rowpar_cap = 0;     // per-row temperature | top_p of the current step
   void* deq_scratch = nullptr; size_t deq_cap = 0;        // [hi | lo] 16-bit copy of one int4 matrix (prefill GEMM)
+  void* sk_ws = nullptr; size_t sk_ws_cap = 0;            // split-K partial tiles of gemm_skinny.hip
+  unsigned* sk_ctr = nullptr; int sk_ctr_cap = 0;         // its per-tile-group arrival counters (zero between launches)
   int32_t* d_next = nullptr;      // tokens sampled by the last step [maxB]
   float* d_logprob = nullptr; float* d_prob0 = nullptr; float* d_rowstats = nullptr; float* d_uniforms = nullptr;
   int32_t* d_topk_ids = nullptr; float* d_topk_lp = nullptr;
@@ -100,6 +102,8 @@ struct mi_engine {
   int opt_attn_mfma = 1;                 // decode attention on the matrix cores where the shape allows
   int opt_tile_weights = 1;
   int opt_prefill_gemm = 1;
+  int opt_skinny_gemm = 1;      // decode steps of 17..64 rows: the split-K weight-streaming GEMM (gemm_skinny.hip)
+  int cur_L = 0;                // tokens per sequence of the forward pass being enqueued
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
                                          // Off: measured on Mistral-7B bf16 B=8 the in-launch seam costs what the kernel
                                          // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
@@ -289,6 +293,39 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
 int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_t es_in, size_t es_out,
               const char* prof) {
   c.force_v1 = e->opt_force_v1;
+  if (e->opt_skinny_gemm && e->cur_L == 1 && gemm_skinny_supported(f.W, c, rows)) {
+    // the decode step of a batch of 17..64 sequences: W is streamed once, K split over workgroups (gemm_skinny.hip).
+    // Decode only: a prefill keeps ONE arithmetic whatever the batch around a sequence (the tile GEMM from 32 rows
+    // up, 16-row launches below), which tests/test_gpu_fullsize.py holds bit for bit.
+    Prof pr(e, prof);
+    if (c.pro == PRO_NORM) {
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream));
+      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+    }
+    c.M = (int)rows;
+    if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {
+      c.lora_t = e->lora_t; c.lora_t_ld = 128;
+      MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
+    }
+    const size_t need = gemm_skinny_ws_bytes(f.W, c, rows);
+    const int groups = gemm_skinny_groups(f.W, c, rows);
+    if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
+      MI_HIP(hipStreamSynchronize(e->stream));
+      if (need > e->sk_ws_cap) {
+        hipFree(e->sk_ws); e->sk_ws = nullptr; e->sk_ws_cap = 0;
+        MI_HIP(hipMalloc(&e->sk_ws, need));
+        e->sk_ws_cap = need;
+      }
+      if (groups > e->sk_ctr_cap) {
+        hipFree(e->sk_ctr); e->sk_ctr = nullptr; e->sk_ctr_cap = 0;
+        const int cap = std::max(groups, 4096);
+        MI_HIP(hipMalloc(&e->sk_ctr, (size_t)cap * sizeof(unsigned)));
+        MI_HIP(hipMemsetAsync(e->sk_ctr, 0, (size_t)cap * sizeof(unsigned), e->stream));
+        e->sk_ctr_cap = cap;
+      }
+    }
+    return launch_gemm_skinny(f.W, c, rows, e->stream, e->sk_ws, e->sk_ctr);
+  }
   if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {
     // prefill: one MFMA tile GEMM over all rows (the RMSNorm runs as its own row-wise kernel)
     Prof pr(e, prof);
@@ -402,6 +439,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
   const int H = d.hidden_size, D = d.head_dim, Hq = d.num_heads, Hkv = d.num_kv_heads, I = d.intermediate_size;
   const int nqkv = (Hq + 2 * Hkv) * D;
   hipStream_t st = e->stream;
+  e->cur_L = L;
 
   auto row_of = [&](int b) { return rows ? rows[b] : b; };
   for (int b = 0; b < B; ++b)
@@ -626,6 +664,7 @@ void mi_engine_destroy(mi_engine* e) {
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
   hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
+  hipFree(e->sk_ws); hipFree(e->sk_ctr);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {
@@ -1004,6 +1043,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "force_generic_gemv") { e->opt_force_v1 = value != 0; return MI_OK; }
   if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
   if (k == "prefill_gemm") { e->opt_prefill_gemm = value != 0; return MI_OK; }
+  if (k == "skinny_gemm") { e->opt_skinny_gemm = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "tile_weights") {

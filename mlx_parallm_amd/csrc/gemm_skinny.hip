@@ -1,0 +1,442 @@
+// gemm_skinny.hip -- weight-streaming GEMM for 17..64 activation rows: the decode step of a large batch
+// (BASELINE configs 4 / 5 put 32 / 64 sequences in one batch) and short prefills.
+//
+// Same operator as gemv_mfma.hip (nn.Linear / nn.QuantizedLinear call sites llama.py:64-67,93,143,160-165,
+// 250-252; qwen3.py:37-40,63,115 with residual / SwiGLU fused), same tile-major weights (repack.hip), same
+// orientation: D[m][n] = sum_k A[m][k] B[k][n], A = activations from LDS, B = W^T straight from HBM.
+//
+// Why another kernel.  gemv_mfma.hip splits K over the eight waves of a workgroup, so every workgroup stages
+// ALL of x in LDS: at 64 rows x 4096 that is 512 KiB per 128 KiB of weights.  The tile GEMM of the prefill
+// (gemm_prefill.hip) has N/128 workgroups and is tuned for thousands of rows: at 32 rows it ran the
+// Mistral-7B step in 17.5 ms where the weights alone stream in 2.3 ms.  Here the op stays what it is at this
+// size -- HBM-bound on the weights -- and is organised around one read of W:
+//
+//   * A workgroup is 8 waves; wave w owns the 16-row tile 8 j + w of W (gate AND up tile for SwiGLU) and
+//     streams it with a rolling prefetch (8 KiB-loads in flight per wave; int4: 4 x 1152 B).
+//   * All eight waves walk the same k range in 256-wide chunks, so one LDS copy of the activation chunk
+//     (MFMA A-fragments, 16 * MT rows x 256 k, double-buffered; the next chunk is fetched into registers at
+//     the top of a chunk and written in its middle) serves eight tiles: x moves L2 -> LDS at MT/8 of the
+//     weight rate instead of MT x.
+//   * N / 128 workgroups cannot fill 256 CUs (o_proj: 32), so K is also split over `ksplit` workgroups.
+//     Partial tiles go to a float32 workspace; the LAST workgroup of a tile group to arrive (one agent-scope
+//     counter per group, no spinning) adds the ksplit partials in slice order -- deterministic -- and runs the
+//     epilogue.  ksplit comes from a small cost model on the host (skinny_plan).
+//   * Two workgroups per CU (<= 66 KiB LDS, <= 128 VGPRs) hide each other's barriers and prologues.
+//
+// RMSNorm is not fused here: the caller runs rmsnorm_rows first (as for the prefill GEMM) -- every workgroup
+// would otherwise need a full pass over its rows before the first MFMA.
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+#include "gemv_phase.h"
+
+namespace mi {
+
+namespace {
+
+using namespace gemv;
+
+constexpr int SK_NW = 8;      // waves (= tiles) per workgroup
+constexpr int SK_KC = 256;    // k per activation chunk
+
+struct SkinnyParams {
+  const void* x; int ldx; int M;
+  const void* w; int N, K;
+  int epi; void* out; int ldo; void* resid; int pair_offset;
+  int ntiles;        // 16-row tiles (tile pairs for SwiGLU)
+  int ksplit;        // workgroups per tile group along K
+  int nchunks;       // ceil(K / 256)
+  float* ws;         // [ksplit][ntiles][NA][MT][64 lanes][4] partial accumulators (ksplit > 1)
+  unsigned* ctr;     // [tile groups] arrival counters, zero between launches
+  const float* lora_t; int lora_t_ld;
+  const float* lora_b0; const float* lora_b1;
+  int lora_row0_0, lora_n_0, lora_rank_0; float lora_scale_0;
+  int lora_row0_1, lora_n_1, lora_rank_1; float lora_scale_1;
+};
+
+template <typename AT, bool Q4, int MT, bool SWIGLU>
+__global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
+  constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
+  constexpr int UK = (Q4 ? 4 : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
+  constexpr int UPC = Q4 ? 2 : 8;           // loads per chunk (a load covers 128 / 32 k)
+  constexpr int CPI = UK > UPC ? UK / UPC : 1;   // chunks per trip of the loop body (the slot ring has UK entries)
+  constexpr int UB = Q4 ? 1152 : 1024;      // bytes of one tile-major block
+  constexpr int FRAG = MB * 512;            // fragment bytes per buffer (MB x 256 x 2)
+  constexpr int BUF = FRAG + (Q4 ? MB * 16 : 0);   // + sum(x) per (64-group, row) for the int4 bias term
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int last_sh;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x / p.ksplit, s = blockIdx.x - grp * p.ksplit;
+  const int tile_raw = grp * SK_NW + wave;
+  const bool valid = tile_raw < p.ntiles;
+  const int tile = valid ? tile_raw : p.ntiles - 1;        // a spare wave re-streams the last tile and stores nothing
+  const int c0 = (s * p.nchunks) / p.ksplit, c1 = ((s + 1) * p.nchunks) / p.ksplit;
+  const int nunits = p.K / (SK_KC / UPC);
+  const int u_begin = c0 * UPC, u_end = min(c1 * UPC, nunits);
+
+  const char* wb[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) wb[a] = (const char*)p.w + (size_t)(tile + a * (p.pair_offset >> 4)) * nunits * UB;
+
+  u32x4 wr[NA][UK];
+  uint32_t sr[NA][Q4 ? UK : 1], br[NA][Q4 ? UK : 1];
+  f32x4 acc[NA][MT];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // STRAIGHT-LINE (see gemv_phase.h issue_u): a unit past the slice re-loads the slice's first block
+  auto issue = [&](int slot, int unit) {
+    const int uc = unit < u_end ? unit : u_begin;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const char* blk = wb[a] + (size_t)uc * UB;
+      wr[a][slot] = __builtin_nontemporal_load((const u32x4*)(blk + lane * 16));
+      if constexpr (Q4) {
+        sr[a][slot] = *(const uint32_t*)(blk + 1024 + c16 * 4);
+        br[a][slot] = *(const uint32_t*)(blk + 1088 + c16 * 4);
+      }
+    }
+  };
+
+  // ---- activation staging: piece q = (row m, 8 k) of a chunk; 8 consecutive lanes read 128 contiguous bytes
+  // of a row.  Piece P of the chunk (dense: k/8; int4: the nibble-order permutation of gemv_phase.h) lands at
+  // slot P * MB + (m ^ ((P & 7) << 1)): writers (8 P x 2 m per 16 lanes) and readers (16 m of one P) both
+  // touch 16 different 16-byte columns.
+  const AT* xrow[MT];
+  int xk[MT], woff[MT], sxoff[MT];
+  bool xm[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int q = tid + i * (SK_NW * 64);
+    const int k8lo = q & 7, r = q >> 3, m = r % MB, k8l = (r / MB) * 8 + k8lo;
+    int P = k8l;
+    if constexpr (Q4) {
+      const int kb = k8l >> 4, sg = (k8l >> 3) & 1, t = k8lo & 1, e = k8lo - t;
+      const int gg = (e == 0) ? 0 : (e == 4) ? 1 : (e == 2) ? 2 : 3;
+      P = ((kb * 2 + sg) * 2 + t) * 4 + gg;
+    }
+    woff[i] = (P * MB + (m ^ ((P & 7) << 1))) * 16;
+    sxoff[i] = FRAG + ((k8l >> 3) * MB + m) * 4;
+    xk[i] = k8l * 8;
+    xm[i] = m < p.M;
+    xrow[i] = (const AT*)p.x + (size_t)min(m, p.M - 1) * p.ldx;
+  }
+  u32x4 xr[MT];
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int k = c * SK_KC + xk[i];
+      xr[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0));
+    }
+  };
+  auto store_x = [&](int c, unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const bool ok = xm[i] && (c * SK_KC + xk[i] < p.K);
+      u32x4 v = ok ? xr[i] : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (Q4) {
+        AT* e = (AT*)&v;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)e[j];
+        AT t2[8];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) { t2[2 * qd] = e[qd]; t2[2 * qd + 1] = e[qd + 4]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = t2[j];
+        sum = lane8_sum(sum);
+        if ((tid & 7) == 0) *(float*)(buf + sxoff[i]) = sum;
+      }
+      *(u32x4*)(buf + woff[i]) = v;
+    }
+  };
+
+  // reader side: fragment of piece P = 4 b + g, rows 16 mt + c16 -> byte (b*4*MB + 16 mt) * 16 + lane_off[b & 1]
+  int lane_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) lane_off[par] = (g * MB + (c16 ^ ((par * 4 + g) << 1))) * 16;
+
+  auto mfma_unit = [&](int slot, int i, const unsigned char* cur) {
+    if constexpr (!Q4) {
+      u32x4 af[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const u32x4*)(cur + lane_off[i & 1] + (i * 4 * MB + mt * 16) * 16);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[a][mt] = mfma16<AT>(af[mt], wr[a][slot], acc[a][mt]);
+    } else {
+      // (see Phase::mfma_u) after the swap {x,y} = quant group A, {z,w} = group B in every lane
+      uint32_t dw[NA][4];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const u32x4 v = wr[a][slot];
+        auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+        dw[a][0] = r0[0]; dw[a][1] = r1[0]; dw[a][2] = r0[1]; dw[a][3] = r1[1];
+      }
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        u32x4 wq[NA][2];
+        float sc[NA], bb[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          wq[a][0] = unpack_q4<AT>(dw[a][sg * 2 + 0]);
+          wq[a][1] = unpack_q4<AT>(dw[a][sg * 2 + 1]);
+          sc[a] = (float)((const AT*)&sr[a][slot])[sg];
+          bb[a] = (float)((const AT*)&br[a][slot])[sg] - Magic<AT>::offs * sc[a];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int pb = ((i * 2 + sg) * 2) * 4 * MB + mt * 16;
+          const u32x4 af0 = *(const u32x4*)(cur + lane_off[0] + pb * 16);
+          const u32x4 af1 = *(const u32x4*)(cur + lane_off[1] + (pb + 4 * MB) * 16);
+          const f32x4 sxv = *(const f32x4*)(cur + FRAG + ((i * 2 + sg) * MB + mt * 16 + g * 4) * 4);
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mfma16<AT>(af0, wq[a][0], d);
+            d = mfma16<AT>(af1, wq[a][1], d);
+            acc[a][mt].x = fmaf(sc[a], d.x, fmaf(bb[a], sxv.x, acc[a][mt].x));
+            acc[a][mt].y = fmaf(sc[a], d.y, fmaf(bb[a], sxv.y, acc[a][mt].y));
+            acc[a][mt].z = fmaf(sc[a], d.z, fmaf(bb[a], sxv.z, acc[a][mt].z));
+            acc[a][mt].w = fmaf(sc[a], d.w, fmaf(bb[a], sxv.w, acc[a][mt].w));
+          }
+        }
+      }
+    }
+  };
+
+  // ================= prologue: activations first (older in the vmcnt queue), then the first UK blocks
+  unsigned char* cur = smem;
+  unsigned char* nxt = smem + BUF;
+  load_x(c0);
+#pragma unroll
+  for (int u = 0; u < UK; ++u) issue(u, u_begin + u);
+  store_x(c0, cur);
+  __syncthreads();
+
+  // ================= the slice
+  for (int c = c0; c < c1; c += CPI) {
+#pragma unroll
+    for (int ci = 0; ci < CPI; ++ci) {
+      const int cc = c + ci;                      // (int4: the second chunk of a trip may lie past the slice)
+      const int cn = min(cc + 1, c1 - 1);
+      load_x(cn);
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        const int slot = (ci * UPC + i) % UK, unit = cc * UPC + i;
+        if (unit < u_end) mfma_unit(slot, i, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(slot, unit + UK);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == UPC / 2) store_x(cn, nxt);
+      }
+      __syncthreads();                            // the next chunk's fragments are complete; this chunk's are free
+      unsigned char* t = cur; cur = nxt; nxt = t;
+    }
+  }
+
+  // ================= split K: publish the partial tile; the last workgroup of the group adds them up.
+  // Hand-off as in gemv_phase.h seam_arrive: partials are stored write-through (agent-scope atomics -> sc1, they do not
+  // stay dirty in this XCD's L2), every wave drains its stores, the workgroup is counted, and the reader uses
+  // agent-scope loads.  No release / acquire FENCES: on this part they write back / invalidate the whole L2 of the
+  // XCD per wave, which made the launch several times slower than the streaming itself.
+  if (p.ksplit > 1) {
+    if (valid) {
+      unsigned long long* wp = (unsigned long long*)(p.ws + (((size_t)(s * p.ntiles + tile) * (NA * MT)) * 64 + lane) * 4);
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v = acc[a][mt];
+          unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+          unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+          __hip_atomic_store(wp + (size_t)(a * MT + mt) * 128, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(wp + (size_t)(a * MT + mt) * 128 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have left
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&p.ctr[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (unsigned)(p.ksplit - 1);
+      if (last) __hip_atomic_store(&p.ctr[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+      last_sh = last;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int s2 = 0; s2 < p.ksplit; ++s2) {     // slice order, whoever arrived last
+        const float* rp = p.ws + (((size_t)(s2 * p.ntiles + tile) * (NA * MT)) * 64 + lane) * 4;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const u32x4 v = load16_agent(rp + (size_t)(a * MT + mt) * 256);
+            acc[a][mt].x += __uint_as_float(v.x); acc[a][mt].y += __uint_as_float(v.y);
+            acc[a][mt].z += __uint_as_float(v.z); acc[a][mt].w += __uint_as_float(v.w);
+          }
+      }
+    }
+  }
+  if (!valid) return;
+
+  // ================= epilogue: lane (c16, g) holds y[16 mt + 4 g + r][16 tile + c16]
+  const int n = tile * 16 + c16;
+  AT* out = (AT*)p.out;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mt * 16 + g * 4 + r;
+      if (m >= p.M) continue;
+      const float y0 = acc[0][mt][r];
+      if constexpr (SWIGLU) {
+        const float gt = (float)(AT)y0, up = (float)(AT)acc[NA - 1][mt][r];
+        const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+        const float sl = (float)(AT)(gt * sig);
+        out[(size_t)m * p.ldo + n] = (AT)(sl * up);
+      } else {
+        float y = (float)(AT)y0;
+        if (p.lora_t != nullptr) {
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            const int r0 = sl ? p.lora_row0_1 : p.lora_row0_0;
+            const int ln = sl ? p.lora_n_1 : p.lora_n_0;
+            const int rk = sl ? p.lora_rank_1 : p.lora_rank_0;
+            const float* lb = sl ? p.lora_b1 : p.lora_b0;
+            if (lb != nullptr && n >= r0 && n < r0 + ln) {
+              const float* tt = p.lora_t + (size_t)m * p.lora_t_ld + sl * (p.lora_t_ld / 2);
+              float z = 0.f;
+              for (int j = 0; j < rk; ++j) z = fmaf(tt[j], lb[(size_t)j * ln + (n - r0)], z);
+              z = (sl ? p.lora_scale_1 : p.lora_scale_0) * z;
+              y = (float)(AT)(y + (float)(AT)z);
+            }
+          }
+        }
+        if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
+        else if (p.epi == EPI_STORE_F32) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
+        else {
+          AT* h = (AT*)p.resid;
+          h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+        }
+      }
+    }
+}
+
+int skinny_mt(size_t rows) { return (int)((rows + 15) / 16); }
+
+struct SkinnyPlan { int ntiles, ngroups, nchunks, ksplit, mt, na; size_t ws_bytes; };
+
+// ksplit: time of the launch ~ rounds x (bytes one workgroup moves) / (rate one CU gets), with the partial
+// tiles (written, then read once) counted as extra bytes.  A lone workgroup cannot pull more than ~40 GB/s
+// (bytes in flight / latency), so too few workgroups are slow even though HBM is idle.
+SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
+  SkinnyPlan pl{};
+  pl.na = c.epi == EPI_SWIGLU ? 2 : 1;
+  pl.mt = skinny_mt(rows);
+  pl.ntiles = (c.epi == EPI_SWIGLU ? c.pair_offset : W.N) / 16;
+  pl.ngroups = (pl.ntiles + SK_NW - 1) / SK_NW;
+  pl.nchunks = (W.K + SK_KC - 1) / SK_KC;
+  const double cus = gemv_cu_count(), bw = 6.3e12, r_max = 40e9;
+  const double bpe = wk_is_quant(W.wk) ? 0.5625 : 2.0;
+  const double unit_p = 2.0 * SK_NW * 16 * pl.na * pl.mt * 16 * 4;          // written + read
+  double best = 0.0;
+  pl.ksplit = 1;
+  for (int s = 1; s <= std::min(16, pl.nchunks); ++s) {
+    const double units = (double)pl.ngroups * s;
+    const double unit_w = (double)SK_NW * 16 * pl.na * bpe * SK_KC * ((pl.nchunks + s - 1) / s);
+    const double rate = std::min(r_max, bw / std::min(units, cus));
+    const double t = std::ceil(units / cus) * (unit_w + (s > 1 ? unit_p : 0.0)) / rate;
+    if (s == 1 || t < best * 0.97) { best = t; pl.ksplit = s; }            // a larger split has to earn its partials
+  }
+  pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024 : 0;
+  return pl;
+}
+
+template <typename AT, bool Q4, int MT, bool SWIGLU>
+int launch_k(const SkinnyParams& p, int grid, hipStream_t st) {
+  auto kern = skinny_kernel<AT, Q4, MT, SWIGLU>;
+  const size_t lds = 2 * ((size_t)16 * MT * 512 + (Q4 ? 16 * MT * 16 : 0));
+  static bool attr_done = false;
+  if (!attr_done) {
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 512 + 64 * 16)));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(SK_NW * 64), lds, st, p);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+template <typename AT, bool Q4, bool SWIGLU>
+int launch_mt(const SkinnyParams& p, int mt, int grid, hipStream_t st) {
+  switch (mt) {
+    case 2: return launch_k<AT, Q4, 2, SWIGLU>(p, grid, st);
+    case 3: return launch_k<AT, Q4, 3, SWIGLU>(p, grid, st);
+    case 4: return launch_k<AT, Q4, 4, SWIGLU>(p, grid, st);
+  }
+  return fail(MI_ERR_INVALID, "gemm_skinny: 17..64 rows");
+}
+
+template <typename AT>
+int launch_at(const SkinnyParams& p, bool q4, bool swiglu, int mt, int grid, hipStream_t st) {
+  if (q4) return swiglu ? launch_mt<AT, true, true>(p, mt, grid, st) : launch_mt<AT, true, false>(p, mt, grid, st);
+  return swiglu ? launch_mt<AT, false, true>(p, mt, grid, st) : launch_mt<AT, false, false>(p, mt, grid, st);
+}
+
+}  // namespace
+
+bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
+  if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
+  if (rows <= 16 || rows > 64) return false;
+  const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
+  const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
+                  W.K % 128 == 0;
+  if (!dense && !q4) return false;
+  if (W.K % 32 != 0 || c.ldx % 8 != 0) return false;
+  const int n = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
+  return n % 16 == 0;
+}
+
+size_t gemm_skinny_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ws_bytes; }
+int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ngroups; }
+
+// c.pro must be PRO_NONE (normalise first); `ws` holds gemm_skinny_ws_bytes(), `ctr` gemm_skinny_groups() zeroed words
+int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr, int ksplit) {
+  if (c.pro != PRO_NONE) return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first");
+  SkinnyPlan pl = skinny_plan(W, c, rows);
+  if (ksplit > 0) {
+    pl.ksplit = std::min(ksplit, pl.nchunks);
+    pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024 : 0;
+  }
+  if (pl.ksplit > 1 && (ws == nullptr || ctr == nullptr)) return fail(MI_ERR_INVALID, "gemm_skinny: workspace missing");
+  SkinnyParams p{};
+  p.x = c.x; p.ldx = c.ldx; p.M = (int)rows;
+  p.w = W.w; p.N = W.N; p.K = W.K;
+  p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.epi == EPI_SWIGLU ? c.pair_offset : 0;
+  p.ntiles = pl.ntiles; p.ksplit = pl.ksplit; p.nchunks = pl.nchunks;
+  p.ws = (float*)ws; p.ctr = ctr;
+  p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;
+  p.lora_b0 = W.lora_b[0]; p.lora_b1 = W.lora_b[1];
+  p.lora_row0_0 = W.lora_row0[0]; p.lora_n_0 = W.lora_n[0]; p.lora_rank_0 = W.lora_rank[0]; p.lora_scale_0 = W.lora_scale[0];
+  p.lora_row0_1 = W.lora_row0[1]; p.lora_n_1 = W.lora_n[1]; p.lora_rank_1 = W.lora_rank[1]; p.lora_scale_1 = W.lora_scale[1];
+  const bool q4 = wk_is_quant(W.wk), sw = c.epi == EPI_SWIGLU;
+  const int grid = pl.ngroups * pl.ksplit;
+  return c.act == MI_BF16 ? launch_at<bf16>(p, q4, sw, pl.mt, grid, st) : launch_at<f16>(p, q4, sw, pl.mt, grid, st);
+}
+
+int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ksplit; }
+
+}  // namespace mi

@@ -74,6 +74,16 @@ int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st);
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
                         hipStream_t st);
 
+// 17..64 rows (decode steps of large batches, short prefills): weight-streaming split-K GEMM (gemm_skinny.hip).
+// c.pro must be PRO_NONE; `ws` >= gemm_skinny_ws_bytes(), `ctr` >= gemm_skinny_groups() words that are zero between
+// launches (the kernel leaves them zero); ksplit = 0 lets the cost model choose.
+bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows);
+size_t gemm_skinny_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows);
+int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows);
+int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows);
+int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr,
+                       int ksplit = 0);
+
 // tile-major weight layout (repack.hip)
 bool tiled_supported(int wk, int N, int K, int group);
 size_t tiled_bytes(int wk, int N, int K);

@@ -78,6 +78,38 @@ int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters,
   return finish();
 }
 
+// gemm_skinny.hip on its own: a->M in 17..64, a->pro must be MI_PRO_NONE; ksplit 0 = the cost model's choice
+// (*ksplit_used returns it); iters >= 1 additionally times `iters` back-to-back launches.
+int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters, float* avg_ms) {
+  if (!w || !a) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  const LinearW W = to_linear(w);
+  const GemvCall c = to_call(a);
+  if (!gemm_skinny_supported(W, c, (size_t)c.M)) return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_skinny: call not supported by this kernel");
+  const int groups = gemm_skinny_groups(W, c, (size_t)c.M);
+  void* ws = nullptr; unsigned* ctr = nullptr;
+  MI_HIP(hipMalloc(&ws, (size_t)W.N * 4096 + 1024));                  // 16 slices x N x 64 rows x 4 B: any ksplit
+  MI_HIP(hipMalloc(&ctr, (size_t)groups * sizeof(unsigned)));
+  MI_HIP(hipMemset(ctr, 0, (size_t)groups * sizeof(unsigned)));
+  if (ksplit_used) *ksplit_used = ksplit > 0 ? ksplit : gemm_skinny_ksplit(W, c, (size_t)c.M);
+  int rc = launch_gemm_skinny(W, c, (size_t)c.M, nullptr, ws, ctr, ksplit);
+  if (rc == MI_OK && iters >= 1 && avg_ms) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && rc == MI_OK; ++i) rc = launch_gemm_skinny(W, c, (size_t)c.M, nullptr, ws, ctr, ksplit);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *avg_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  const int rc2 = finish();
+  hipFree(ws); hipFree(ctr);
+  return rc != MI_OK ? rc : rc2;
+}
+
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a) {
   if (!w || !a) return 0;
   return gemv_mfma_supported(to_linear(w), to_call(a)) ? 1 : 0;

@@ -86,3 +86,17 @@ def close_frac(got: np.ndarray, want: np.ndarray, dtype: str, atol: float = 0.0)
     """Fraction of elements further than 2 ulp(dtype) (relative) + atol from the oracle."""
     tol = ULP[dtype] * np.maximum(np.abs(want), np.abs(got)) + atol
     return float(np.mean(np.abs(got - want) > tol))
+
+
+def gemm_skinny(ol: L.OpLinear, x, M, act, *, epi=0, out=None, ldo=0, resid=None, pair_offset=0, ksplit=0, iters=0, ldx=None):
+    """gemm_skinny.hip on its own (17..64 rows) -> (ksplit used, mean launch ms or None)."""
+    a = L.OpGemvArgs()
+    a.x = x.data_ptr(); a.ldx = ldx if ldx is not None else x.shape[-1]; a.M = M
+    a.act = MIDT[act]; a.rnd = 0; a.pro = 0; a.epi = epi; a.norm_w = 0; a.eps = 0.0; a.ldo = ldo
+    a.out = out.data_ptr() if out is not None else 0
+    a.resid = resid.data_ptr() if resid is not None else 0
+    a.pair_offset = pair_offset; a.force_generic = 0
+    torch.cuda.synchronize()
+    used, ms = C.c_int(0), C.c_float(0.0)
+    L.check(L.lib().mi_op_gemm_skinny(C.byref(ol), C.byref(a), int(ksplit), C.byref(used), int(iters), C.byref(ms)))
+    return used.value, (ms.value if iters >= 1 else None)

@@ -1,0 +1,191 @@
+"""Kernel-level parity (-m gpu) of gemm_skinny.hip -- the split-K weight-streaming GEMM the engine uses for 17..64
+activation rows (decode steps of large batches, BASELINE configs 4 / 5) -- against the oracle's matmul, through
+mi_op_gemm_skinny (include/mi355_ops.h).  Tolerances as in test_gpu_kernels.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_quant
+from oracle.numerics import matmul_nt, round_to
+
+pytestmark = pytest.mark.gpu
+
+from mlx_parallm_amd import _lib as L  # noqa: E402
+from gpu_helpers import dev, dev_u32, gemm_skinny, gemv, host, op_linear, to_tiled  # noqa: E402
+from test_gpu_kernels import _assert_close  # noqa: E402
+
+RNG = np.random.default_rng(4321)
+
+
+def _weight(kind, N, K):
+    if kind in ("bf16", "f16"):
+        dt = {"bf16": "bfloat16", "f16": "float16"}[kind]
+        w = round_to(RNG.standard_normal((N, K)).astype(np.float32) * 0.05, dt)
+        wd = dev(w, dt)
+        ol, keep = op_linear(kind, N, K, wd), [wd]
+        assert to_tiled(ol, keep)
+        return ol, w, keep
+    sdt = {"bf16": "bfloat16", "f16": "float16"}[kind.split("_")[1]]
+    w = RNG.standard_normal((N, K)).astype(np.float32) * 0.05
+    packed, scales, biases = ref_quant.quantize(round_to(w, sdt), 64, 4, sdt)
+    pd, sd, bd = dev_u32(packed), dev(scales, sdt), dev(biases, sdt)
+    ol, keep = op_linear(kind, N, K, pd, sd, bd), [pd, sd, bd]
+    assert to_tiled(ol, keep)
+    return ol, ref_quant.dequantize(packed, scales, biases, 64, 4), keep
+
+
+KINDS = [("bfloat16", "bf16"), ("float16", "f16"), ("bfloat16", "q4_bf16"), ("float16", "q4_f16")]
+
+
+@pytest.mark.parametrize("act,kind", KINDS)
+@pytest.mark.parametrize("M,N,K,ksplit", [
+    (17, 80, 128, 1),        # one partial chunk, 5 tiles (3 spare waves)
+    (32, 256, 512, 2),       # two tile groups x two K slices
+    (40, 144, 4608, 5),      # 18 chunks in unequal slices, 48-row fragments
+    (64, 1040, 1024, 0),     # cost model's split, 65 tiles
+    (33, 128, 384, 3),       # last chunk half full (K % 256 = 128)
+])
+def test_store_matches_oracle_and_is_deterministic(act, kind, M, N, K, ksplit):
+    ol, wdense, keep = _weight(kind, N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    xd = dev(x, act)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M + 2, N), 7.0, dtype=xd.dtype, device="cuda")
+        used, _ = gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE, out=out, ldo=N, ksplit=ksplit)
+        assert used >= 1 and (ksplit == 0 or used == ksplit)
+        outs.append(host(out))
+    assert np.array_equal(outs[0], outs[1])                       # slice-order reduction: run-to-run identical
+    assert np.all(outs[0][M:] == 7.0)                             # rows past M are never written
+    _assert_close(outs[0][:M], round_to(matmul_nt(x, wdense), act), act)
+
+
+@pytest.mark.parametrize("act,kind", KINDS)
+def test_epilogues(act, kind):
+    M = 48
+    # residual add (llama.py:188,190), K split over 4 workgroups
+    N, K = 192, 2048
+    ol, wdense, keep = _weight(kind, N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32) * 0.5, act)
+    h = round_to(RNG.standard_normal((M, N)).astype(np.float32), act)
+    want = round_to(h + round_to(matmul_nt(x, wdense), act), act)
+    xd, hd = dev(x, act), dev(h, act)
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_RESID, resid=hd, ldo=N, ksplit=4)
+    _assert_close(host(hd), want, act, scale=4.0)
+    # SwiGLU over a fused gate|up matrix (llama.py:165)
+    I, K = 176, 768
+    ol, wdense, keep = _weight(kind, 2 * I, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    g = round_to(matmul_nt(x, wdense[:I]), act)
+    u = round_to(matmul_nt(x, wdense[I:]), act)
+    sig = round_to(1.0 / (1.0 + np.exp(-g.astype(np.float64))), act)
+    want = round_to(round_to(g * sig, act) * u, act)
+    xd = dev(x, act)
+    for ks in (1, 3):
+        out = torch.zeros((M, I), dtype=xd.dtype, device="cuda")
+        gemm_skinny(ol, xd, M, act, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, ksplit=ks)
+        _assert_close(host(out), want, act)
+    # float32 logits (lm_head)
+    N = 208
+    ol, wdense, keep = _weight(kind, N, K)
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE_F32, out=out, ldo=N, ksplit=2)
+    _assert_close(host(out), round_to(matmul_nt(x, wdense), act), act)
+
+
+def test_rows_agree_with_the_16_row_kernel():
+    """The same rows through gemv_mfma.hip (<= 16 rows per launch): equal up to the rounding of differently ordered
+    float32 sums."""
+    act, M, N, K = "bfloat16", 32, 512, 4096
+    ol, wdense, keep = _weight("bf16", N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    xd = dev(x, act)
+    a = torch.zeros((M, N), dtype=xd.dtype, device="cuda")
+    b = torch.zeros((M, N), dtype=xd.dtype, device="cuda")
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE, out=a, ldo=N)
+    for r in (0, 16):
+        assert gemv(ol, xd[r:r + 16], 16, act, epi=L.EPI_STORE, out=b[r:r + 16], ldo=N)
+    _assert_close(host(a), host(b), act)
+    assert np.mean(host(a) == host(b)) > 0.97
+
+
+# ---- through the engine: decode steps of more than 16 sequences (BASELINE configs 4 / 5: batches of 32 / 64)
+
+from oracle import ref_generate  # noqa: E402
+from mlx_parallm_amd import utils  # noqa: E402
+
+
+def _prompts(cfg, B, L0, seed):
+    rng = np.random.default_rng(seed)
+    toks = rng.integers(3, cfg["vocab_size"], size=(B, L0))
+    for b in range(B):
+        toks[b, :int(rng.integers(0, L0 // 2))] = 1              # left padding (attended, quirk Q1)
+    return toks.astype(np.int32)
+
+
+@pytest.mark.parametrize("B", [17, 40, 64])
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
+def test_large_batch_decode_logits_match_oracle(tiny_dirs, name, B):
+    d, cfg = tiny_dirs[name]
+    model = utils.load_model(d, max_positions=256)
+    ref = ref_generate.load(d, max_pos=256)
+    toks = _prompts(cfg, B, 6, seed=B)
+    kv = model.engine.new_kv(B, capacity=16, kv_dtype="model")
+    cache = ref.make_cache(B, paged=False)
+    model.engine.forward(toks, kv)
+    nxt = np.argmax(ref(toks, cache=cache)[:, -1], axis=-1)[:, None]
+    steps = []
+    for _ in range(3):
+        got = model.engine.forward(nxt.astype(np.int32), kv)
+        want = ref(nxt, cache=cache)[:, -1]
+        assert np.abs(got - want).max() <= 0.08, np.abs(got - want).max()
+        steps.append(got)
+        nxt = np.argmax(want, axis=-1)[:, None]
+    # the same steps through 16-row launches of the M <= 16 kernel: equal up to rounding noise, and not the same path
+    model.engine.set_option("skinny_gemm", 0)
+    kv2 = model.engine.new_kv(B, capacity=16, kv_dtype="model")
+    cache2 = ref.make_cache(B, paged=False)
+    model.engine.forward(toks, kv2)
+    nxt = np.argmax(ref(toks, cache=cache2)[:, -1], axis=-1)[:, None]
+    got2 = model.engine.forward(nxt.astype(np.int32), kv2)
+    assert np.abs(got2 - steps[0]).max() <= 0.08
+    model.engine.close()
+
+
+def test_large_batch_decode_with_lora(tiny_dirs, tmp_path):
+    """BASELINE config 5: int4 weights + LoRA on q / v, a decode batch above 16 rows."""
+    import json
+
+    from safetensors.torch import save_file
+
+    d, cfg = tiny_dirs["llama_q4_bf16"]
+    H, nh, nkv, D = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
+    rng = np.random.default_rng(11)
+    w = {}
+    i = cfg["num_hidden_layers"] - 1
+    for key, n in (("self_attn.q_proj", nh * D), ("self_attn.v_proj", nkv * D)):
+        w[f"model.layers.{i}.{key}.lora_a"] = torch.from_numpy((rng.uniform(-1, 1, (H, 16)) / np.sqrt(H)).astype(np.float32))
+        w[f"model.layers.{i}.{key}.lora_b"] = torch.from_numpy(rng.standard_normal((16, n)).astype(np.float32) * 0.05)
+    ad = tmp_path / "adapter"
+    ad.mkdir()
+    save_file(w, str(ad / "adapters.safetensors"))
+    (ad / "adapter_config.json").write_text(json.dumps({
+        "fine_tune_type": "lora", "num_layers": 1,
+        "lora_parameters": {"rank": 16, "scale": 10.0, "dropout": 0.05, "keys": ["self_attn.q_proj", "self_attn.v_proj"]}}))
+    model = utils.load_model(d, max_positions=256)
+    utils.load_adapters(model, str(ad))
+    ref = ref_generate.load(d, adapter_path=str(ad), max_pos=256)
+    base = ref_generate.load(d, max_pos=256)
+    B = 24
+    toks = _prompts(cfg, B, 6, seed=3)
+    kv = model.engine.new_kv(B, capacity=16, kv_dtype="model")
+    cache, bcache = ref.make_cache(B, paged=False), base.make_cache(B, paged=False)
+    model.engine.forward(toks, kv)
+    nxt = np.argmax(ref(toks, cache=cache)[:, -1], axis=-1)[:, None]
+    base(toks, cache=bcache)
+    got = model.engine.forward(nxt.astype(np.int32), kv)
+    want = ref(nxt, cache=cache)[:, -1]
+    plain = base(nxt, cache=bcache)[:, -1]
+    assert np.abs(want - plain).max() > 0.5                     # the adapter really changes the logits
+    assert np.abs(got - want).max() <= 0.08, np.abs(got - want).max()
+    model.engine.close()

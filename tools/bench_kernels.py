@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--generic", type=int, default=0)
     ap.add_argument("--tiled", type=int, default=1)
+    ap.add_argument("--ksplit", default="0", help="batch > 16 (gemm_skinny): comma-separated K splits to time, 0 = cost model")
     ap.add_argument("--lib", default=None, help="A/B: load this build of libmi355_decode.so instead")
     args = ap.parse_args()
     if args.lib:
@@ -70,6 +71,14 @@ def main():
         a.pair_offset, a.force_generic = (N // 2 if epi == L.EPI_SWIGLU else 0), args.generic
         torch.cuda.synchronize()
         ms = C.c_float(0)
+        if B > 16:                                    # the split-K streaming GEMM (the engine normalises first)
+            a.pro = L.PRO_NONE
+            for ks in [int(v) for v in args.ksplit.split(",")]:
+                used = C.c_int(0)
+                L.check(L.lib().mi_op_gemm_skinny(C.byref(ol), C.byref(a), ks, C.byref(used), args.iters, C.byref(ms)))
+                print(f"{name:8s} N={N:6d} K={K:6d}  {ms.value*1e3:8.1f} us  {wbytes/ms.value/1e6:8.1f} GB/s  (skinny, ksplit={used.value})", flush=True)
+            del keep, w
+            continue
         L.check(L.lib().mi_op_gemv_bench(C.byref(ol), C.byref(a), args.iters, C.byref(ms)))
         print(f"{name:8s} N={N:6d} K={K:6d}  {ms.value*1e3:8.1f} us  {wbytes/ms.value/1e6:8.1f} GB/s  (mfma={L.lib().mi_op_gemv_uses_mfma(C.byref(ol), C.byref(a))})", flush=True)
         del keep, w
