@@ -299,7 +299,7 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     // up, 16-row launches below), which tests/test_gpu_fullsize.py holds bit for bit.
     Prof pr(e, prof);
     if (c.pro == PRO_NORM) {
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream));
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
     c.M = (int)rows;
@@ -422,7 +422,10 @@ int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L, const int32_t* rows = 
   for (int b = 0; b < B; ++b) mx = std::max(mx, kv->h_off[rows ? rows[b] : b] + 1);
   int ns = (256 + B * Hkv - 1) / (B * Hkv);
   ns = std::min(ns, std::max(1, mx / 64));
-  ns = std::max(ns, (mx + 1023) / 1024);     // long contexts: at most four 256-key rounds per workgroup
+  // long contexts: at most four 256-key rounds per workgroup -- eight when the batch alone fills the CUs (every extra
+  // workgroup then costs a prologue and a merge on a CU that is already busy)
+  const int per_wg = B * Hkv >= 256 ? 2048 : 1024;
+  ns = std::max(ns, (mx + per_wg - 1) / per_wg);
   return std::max(1, std::min(ns, 16));
 }
 

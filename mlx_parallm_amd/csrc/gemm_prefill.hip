@@ -332,6 +332,69 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const AT* x, int ldx,
   }
 }
 
+// The same operator with one 256-thread workgroup per row and the row held in registers (NP 16-byte pieces per
+// thread): for the few rows of a decode step (gemm_skinny.hip), where one wave per row means a handful of
+// workgroups walking their rows in dependent L2 round trips (9 us at 32 x 4096; this one: one round trip).
+template <typename AT, int NP>
+__global__ __launch_bounds__(256) void rmsnorm_row_block_kernel(const AT* x, int ldx, const AT* w, AT* out, int ldo, int H,
+                                                                float eps) {
+  __shared__ float part[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const AT* xr = x + (size_t)row * ldx;
+  u32x4 v[NP], wv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int k = (tid + i * 256) * 8;
+    const int kc = k < H ? k : 0;
+    v[i] = *(const u32x4*)(xr + kc);
+    wv[i] = *(const u32x4*)(w + kc);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if ((tid + i * 256) * 8 < H) {
+      const AT* e = (const AT*)&v[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)e[j]; ss = fmaf(f, f, ss); }
+    }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  const float rs = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int k = (tid + i * 256) * 8;
+    if (k < H) {
+      AT* e = (AT*)&v[i];
+      const AT* we = (const AT*)&wv[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const AT xn = (AT)((float)e[j] * rs);
+        e[j] = (AT)((float)xn * (float)we[j]);
+      }
+      *(u32x4*)(out + (size_t)row * ldo + k) = v[i];
+    }
+  }
+}
+
+template <typename AT>
+int launch_rmsnorm_block(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, hipStream_t st) {
+  const int np = (H / 8 + 255) / 256;
+  const dim3 grid(rows), block(256);
+#define GO(NP) hipLaunchKernelGGL((rmsnorm_row_block_kernel<AT, NP>), grid, block, 0, st, (const AT*)x, ldx, (const AT*)w, (AT*)out, ldo, H, eps)
+  switch (np) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    default: return fail(MI_ERR_UNSUPPORTED, "rmsnorm (one workgroup per row): hidden size above 8192");
+  }
+#undef GO
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 }  // namespace
 
 bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
@@ -349,8 +412,12 @@ bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
 }
 
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
-                        hipStream_t st) {
+                        hipStream_t st, bool block_per_row) {
   if (H % 8 != 0) return fail(MI_ERR_UNSUPPORTED, "rmsnorm_rows: hidden size must be a multiple of 8");
+  if (block_per_row && H <= 8192) {
+    if (act == MI_BF16) return launch_rmsnorm_block<bf16>(x, ldx, w, out, ldo, rows, H, eps, st);
+    if (act == MI_F16) return launch_rmsnorm_block<f16>(x, ldx, w, out, ldo, rows, H, eps, st);
+  }
   const dim3 grid((rows + 3) / 4), block(256);
   if (act == MI_BF16)
     hipLaunchKernelGGL(rmsnorm_rows_kernel<bf16>, grid, block, 0, st, (const bf16*)x, ldx, (const bf16*)w, (bf16*)out, ldo, rows, H, eps);

@@ -71,8 +71,10 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
 // int4 (tile-major) -> 16-bit tile-major [hi | lo], K' = 2K: the operand of the prefill GEMM for quantised weights
 size_t dequant_hilo_bytes(int N, int K);
 int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st);
+// block_per_row: one workgroup per row, row in registers -- for the few rows of a decode step (default: one wave
+// per row, the prefill's kernel; the two add the squares in different orders)
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
-                        hipStream_t st);
+                        hipStream_t st, bool block_per_row = false);
 
 // 17..64 rows (decode steps of large batches, short prefills): weight-streaming split-K GEMM (gemm_skinny.hip).
 // c.pro must be PRO_NONE; `ws` >= gemm_skinny_ws_bytes(), `ctr` >= gemm_skinny_groups() words that are zero between

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Kernel-time breakdown of the decode step at another batch size (run from the repo root through gpurun):
+#   tools/profile_batch.sh <batch> [workload]
+set -eo pipefail
+B=${1:-32}
+WL=${2:-mistral-7b-bf16}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_b$B
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ROOT/bench.py --workload $WL --batch $B --steps 32 --warmup 4 --no-cpu-baseline --no-prefill-timing > "$OUT/bench.json" 2> "$OUT/stats.err"
+python3 "$ROOT/tools/summarize_prof.py" stats "$OUT/stats" "$ROOT/gpurun_out/b${B}_${WL}_kernel_stats.csv" \
+  "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --batch $B --steps 32 --warmup 4 --no-prefill-timing"
+grep '^{' "$OUT/bench.json" > "$ROOT/gpurun_out/b${B}_${WL}_bench.json"
+rm -rf "$OUT/stats"
