@@ -77,21 +77,26 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- X tile loads: 128 rows x 8 chunks of 16 B; thread -> chunks tid, tid+256, ...
+  // (straight-line: rows past M read row M - 1 and are zeroed on the way into LDS -- see gemm_tile256_kernel)
   u32x4 areg[4];
-  auto load_a = [&](int ks) {
+  const AT* arow[4];
+  bool aok[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
-      const int gm = m0 + row;
-      areg[i] = u32x4{0u, 0u, 0u, 0u};
-      if (gm < p.M) areg[i] = *(const u32x4*)(x + (size_t)gm * p.ldx + (ks * BK) % p.ka + kq * 8);
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
+    aok[i] = m0 + row < p.M;
+    arow[i] = x + (size_t)min(m0 + row, p.M - 1) * p.ldx + kq * 8;
+  }
+  auto load_a = [&](int ks) {
+    const int ka = (ks * BK) % p.ka;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[i] = *(const u32x4*)(arow[i] + ka);
   };
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
-      *(u32x4*)&As[buf][row][kq * 8] = areg[i];
+      *(u32x4*)&As[buf][row][kq * 8] = aok[i] ? areg[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
   u32x4 breg[3][4][2];     // [set][n tile][k block]; W fragments are fetched two K steps ahead
@@ -116,8 +121,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
   auto step = [&](int ks, auto set_tag) {
     constexpr int SET = decltype(set_tag)::value;
     const int cur = ks & 1;
-    if (ks + 1 < nk) load_a(ks + 1);
-    if (ks + 2 < nk) load_b((SET + 2) % 3, ks + 2);
+    load_a(min(ks + 1, nk - 1));
+    load_b((SET + 2) % 3, min(ks + 2, nk - 1));
+    __builtin_amdgcn_sched_barrier(0);           // the loads stay ahead of this step's MFMAs
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       u32x4 af[4];
@@ -186,8 +192,15 @@ constexpr int BM2 = 256, BN2 = 256;
 constexpr int A2_BYTES = BM2 * LDA * 2;                 // one X image (rows padded to 144 B)
 constexpr int B2_BYTES = BN2 * BK * 2;                  // one W image: 16 row tiles x 2 k blocks x 1 KiB
 constexpr int LDS2_BYTES = 2 * (A2_BYTES + B2_BYTES);
+constexpr int AFR = 4;                                  // A fragments in flight from LDS (ring): item i + 3 is read while item i multiplies
+constexpr int STORE_AT = 11;                            // the item (of 16 per K step) after which the next tile is written to LDS
 
-template <typename AT, bool SWIGLU>
+// BD ("B direct", A/B variant behind MI_GEMM_B_DIRECT): the W fragments do not go through LDS -- in the tile-major
+// layout a fragment is one contiguous KiB, so each wave loads the 8 fragments of its four N tiles for the NEXT K step
+// straight into a second register set (two sets in turn, the K loop is unrolled by two); LDS then carries only the X
+// tile (16 instead of 24 fragment reads per wave and step, half the stores).  Measured 2 % SLOWER than both operands
+// in LDS (68.5 k vs 69.9 k prefill tok/s): the LDS pipe was not the limit, the instruction order was (below).
+template <typename AT, bool SWIGLU, bool BD>
 __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,57 +228,117 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- global -> registers: X 256 rows x 8 chunks = 2048 pieces, W 16 tiles x 2 k blocks x 64 lanes = 2048 pieces
-  u32x4 areg[4], breg[4];
-  auto load_ab = [&](int ks) {
+  // ---- global -> registers: X 256 rows x 8 chunks = 2048 pieces, W 16 tiles x 2 k blocks x 64 lanes = 2048 pieces.
+  // STRAIGHT-LINE loads (no exec mask, no branch): a load under a condition makes hipcc drain the vmcnt queue at the
+  // join -- here that was an exposed L2 round trip per K step.  Rows past M read row M - 1 and are zeroed on the
+  // way into LDS; the step after the last re-reads the last step.
+  constexpr int NB = BD ? 1 : 4;
+  u32x4 areg[4], breg[NB];
+  const AT* arow[4];
+  const char* brow[NB];
+  bool aok[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
-      const int gm = m0 + row;
-      areg[i] = u32x4{0u, 0u, 0u, 0u};
-      if (gm < p.M) areg[i] = *(const u32x4*)(x + (size_t)gm * p.ldx + (ks * BK) % p.ka + kq * 8);
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
+    aok[i] = m0 + row < p.M;
+    arow[i] = x + (size_t)min(m0 + row, p.M - 1) * p.ldx + kq * 8;
+    if constexpr (!BD) {
+      const int s = c >> 7, kb = (c >> 6) & 1, l = c & 63;
+      brow[i] = (const char*)p.w + ((size_t)w_tile_of(s) * (p.K / 32) + (size_t)kb) * 1024 + l * 16;
     }
+  }
+  const char* bptr[4];                                   // BD: this wave's four N tiles, lane-linear
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i, s = c >> 7, kb = (c >> 6) & 1, l = c & 63;
-      const char* blk = (const char*)p.w + ((size_t)w_tile_of(s) * (p.K / 32) + (size_t)(ks * 2 + kb)) * 1024;
-      breg[i] = *(const u32x4*)(blk + l * 16);
+  for (int nt = 0; nt < 4; ++nt) bptr[nt] = (const char*)p.w + (size_t)w_tile_of(wn * 4 + nt) * (p.K / 32) * 1024 + lane * 16;
+  auto load_a = [&](int ks) {
+    const int ka = (ks * BK) % p.ka;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[i] = *(const u32x4*)(arow[i] + ka);
+    if constexpr (!BD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) breg[i] = *(const u32x4*)(brow[i] + (size_t)ks * 2048);
     }
+  };
+  auto load_bd = [&](int ks, u32x4 (&dst)[2][4]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dst[kb][nt] = *(const u32x4*)(bptr[nt] + (size_t)(ks * 2 + kb) * 1024);
   };
   auto store_ab = [&](int buf) {
     AT* A = a_img(buf);
-    unsigned char* B = b_img(buf);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
-      *(u32x4*)&A[row * LDA + kq * 8] = areg[i];
+      *(u32x4*)&A[row * LDA + kq * 8] = aok[i] ? areg[i] : u32x4{0u, 0u, 0u, 0u};
     }
+    if constexpr (!BD) {
+      unsigned char* B = b_img(buf);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(B + (size_t)(tid + 512 * i) * 16) = breg[i];     // (slot, kb, lane) order = piece index
+      for (int i = 0; i < 4; ++i) *(u32x4*)(B + (size_t)(tid + 512 * i) * 16) = breg[i];     // (slot, kb, lane) order = piece index
+    }
   };
 
-  load_ab(0);
-  store_ab(0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
+  u32x4 bset0[2][4], bset1[2][4];                        // BD: the W fragments of the current / the next K step
+  // one K step: `bc` holds this step's W fragments (BD), `bn` receives the next step's
+  auto step = [&](int ks, u32x4 (&bc)[2][4], u32x4 (&bn)[2][4]) {
     const int cur = ks & 1;
-    if (ks + 1 < nk) load_ab(ks + 1);
+    load_a(min(ks + 1, nk - 1));
+    if constexpr (BD) load_bd(min(ks + 1, nk - 1), bn);
+    __builtin_amdgcn_sched_barrier(0);           // keep the loads HERE, a whole step of MFMAs ahead of their use (hipcc
+                                                 // otherwise sinks them next to the LDS stores at the bottom of the step)
     const AT* A = a_img(cur);
     const unsigned char* B = b_img(cur);
+    // 16 (k block, M tile) items of 4 MFMAs; the A fragment of item i + 1 is read while item i multiplies (two
+    // registers in turn -- with one, every LDS round trip sat between two groups of four MFMAs), the W fragments of
+    // the second k block arrive during the first
+    u32x4 bf[2][4], af[AFR];
+    auto a_frag = [&](int it) {
+      return *(const u32x4*)&A[(wm * 128 + (it & 7) * 16 + c16) * LDA + (it >> 3) * 32 + g * 8];
+    };
+    if constexpr (!BD) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      u32x4 bf[4];
+      for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + 0) * 64 + lane) * 16);
+    }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bf[nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + kb) * 64 + lane) * 16);
+    for (int i = 0; i < AFR - 1; ++i) af[i] = a_frag(i);
+    // the order below is imposed on hipcc's scheduler (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA); left
+    // alone it bunches the fragment reads and waits for them in front of single MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, (BD ? 0 : 4) + AFR - 1, 0);
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        const u32x4 af = *(const u32x4*)&A[(wm * 128 + mt * 16 + c16) * LDA + kb * 32 + g * 8];
+    for (int it = 0; it < 16; ++it) {
+      if (it + AFR - 1 < 16) af[(it + AFR - 1) % AFR] = a_frag(it + AFR - 1);
+      if constexpr (!BD) {
+        if (it == 3) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<AT>(af, bf[nt], acc[mt][nt]);
+          for (int nt = 0; nt < 4; ++nt) bf[1][nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + 1) * 64 + lane) * 16);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[it & 7][nt] = mfma16<AT>(af[it % AFR], BD ? bc[it >> 3][nt] : bf[it >> 3][nt], acc[it & 7][nt]);
+      if (it + AFR - 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (!BD && it == 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if (it == STORE_AT) {
+        // the next step's tile goes into the other buffer (its readers finished before the last barrier) three
+        // quarters through this step: the loads have had that long to arrive, and the end of the step is then only
+        // the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        store_ab(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (ks + 1 < nk) store_ab(cur ^ 1);          // the other buffer: its readers finished before the last barrier
     __syncthreads();
+  };
+
+  load_a(0);
+  if constexpr (BD) load_bd(0, bset0);
+  store_ab(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ks += 2) {
+    step(ks, bset0, bset1);
+    if (ks + 1 < nk) step(ks + 1, bset1, bset0);
   }
 
   // ---- epilogue: lane (c16, g) holds C[m = 4g + r][n = c16] of every 16 x 16 tile
@@ -443,12 +516,17 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
   const bool sw = c.epi == EPI_SWIGLU;
   const int ncols = sw ? c.pair_offset : W.N;
   static const bool small_only = getenv("MI_GEMM_TILE128") != nullptr;        // A/B: always the 128 x 128 kernel
+  static const bool b_in_lds = getenv("MI_GEMM_B_DIRECT") == nullptr;         // A/B: set = W fragments straight from global
   if (rows >= 256 && !small_only) {                      // both operands through LDS (gemm_tile256_kernel)
     const int bn = sw ? 128 : BN2;
     const dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
-#define GO256(T, S) do { auto k = gemm_tile256_kernel<T, S>; \
-      MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
-      hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } while (0)
+#define GO256(T, S) do { \
+      if (b_in_lds) { auto k = gemm_tile256_kernel<T, S, false>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
+        hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } \
+      else { auto k = gemm_tile256_kernel<T, S, true>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * A2_BYTES)); \
+        hipLaunchKernelGGL(k, grid2, block2, 2 * A2_BYTES, st, p); } } while (0)
     if (c.act == MI_BF16) { if (sw) GO256(bf16, true); else GO256(bf16, false); }
     else { if (sw) GO256(f16, true); else GO256(f16, false); }
 #undef GO256
