@@ -193,6 +193,7 @@ constexpr int A2_BYTES = BM2 * LDA * 2;                 // one X image (rows pad
 constexpr int B2_BYTES = BN2 * BK * 2;                  // one W image: 16 row tiles x 2 k blocks x 1 KiB
 constexpr int LDS2_BYTES = 2 * (A2_BYTES + B2_BYTES);
 constexpr int AFR = 4;                                  // A fragments in flight from LDS (ring): item i + 3 is read while item i multiplies
+constexpr int SYNC_AT = 13;                             // the item in front of which the K step's barrier sits
 constexpr int STORE_AT = 11;                            // the item (of 16 per K step) after which the next tile is written to LDS
 
 // BD ("B direct", A/B variant behind MI_GEMM_B_DIRECT): the W fragments do not go through LDS -- in the tile-major
@@ -280,6 +281,20 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
   };
 
   u32x4 bset0[2][4], bset1[2][4];                        // BD: the W fragments of the current / the next K step
+  // The fragment pipeline runs ACROSS the K steps: 16 (k block, M tile) items of 4 MFMAs per step; the A fragment of
+  // item i + 3 is read from LDS while item i multiplies (ring of AFR registers; 16 % AFR == 0, so the ring index carries
+  // over), and for the last three items of a step "item i + 3" is item 0..2 of the NEXT step, read from the other
+  // buffer.  That buffer is complete once every wave has stored its share (after item STORE_AT) -- so the step's one
+  // barrier sits in front of item SYNC_AT, not at the end of the step, and the wait for the first fragments of a
+  // step hides behind the previous step's last 12 MFMAs instead of stopping every wave of the workgroup at once.
+  u32x4 bf[2][4], af[AFR];
+  auto a_frag = [&](const AT* A, int it) {
+    return *(const u32x4*)&A[(wm * 128 + (it & 7) * 16 + c16) * LDA + (it >> 3) * 32 + g * 8];
+  };
+  auto b_frags = [&](const unsigned char* B, int kb, u32x4 (&dst)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dst[nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + kb) * 64 + lane) * 16);
+  };
   // one K step: `bc` holds this step's W fragments (BD), `bn` receives the next step's
   auto step = [&](int ks, u32x4 (&bc)[2][4], u32x4 (&bn)[2][4]) {
     const int cur = ks & 1;
@@ -288,54 +303,45 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);           // keep the loads HERE, a whole step of MFMAs ahead of their use (hipcc
                                                  // otherwise sinks them next to the LDS stores at the bottom of the step)
     const AT* A = a_img(cur);
-    const unsigned char* B = b_img(cur);
-    // 16 (k block, M tile) items of 4 MFMAs; the A fragment of item i + 1 is read while item i multiplies (two
-    // registers in turn -- with one, every LDS round trip sat between two groups of four MFMAs), the W fragments of
-    // the second k block arrive during the first
-    u32x4 bf[2][4], af[AFR];
-    auto a_frag = [&](int it) {
-      return *(const u32x4*)&A[(wm * 128 + (it & 7) * 16 + c16) * LDA + (it >> 3) * 32 + g * 8];
-    };
-    if constexpr (!BD) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + 0) * 64 + lane) * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < AFR - 1; ++i) af[i] = a_frag(i);
-    // the order below is imposed on hipcc's scheduler (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA); left
-    // alone it bunches the fragment reads and waits for them in front of single MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x100, (BD ? 0 : 4) + AFR - 1, 0);
+    const AT* An = a_img(cur ^ 1);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-      if (it + AFR - 1 < 16) af[(it + AFR - 1) % AFR] = a_frag(it + AFR - 1);
+      if (it == SYNC_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                         // the other buffer holds the next step's tile; this step's reads are done
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int nx = it + AFR - 1;
+      af[nx % AFR] = nx < 16 ? a_frag(A, nx) : a_frag(An, nx - 16);
       if constexpr (!BD) {
-        if (it == 3) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) bf[1][nt] = *(const u32x4*)(B + (size_t)(((wn * 4 + nt) * 2 + 1) * 64 + lane) * 16);
-        }
+        if (it == 3) b_frags(b_img(cur), 1, bf[1]);
+        if (it == SYNC_AT) b_frags(b_img(cur ^ 1), 0, bf[0]);     // (bf[0] is dead since item 7)
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[it & 7][nt] = mfma16<AT>(af[it % AFR], BD ? bc[it >> 3][nt] : bf[it >> 3][nt], acc[it & 7][nt]);
-      if (it + AFR - 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (!BD && it == 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      // the order is imposed on hipcc's scheduler (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA); left alone
+      // it bunches the fragment reads and waits for them in front of single MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (!BD && (it == 3 || it == SYNC_AT)) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       if (it == STORE_AT) {
-        // the next step's tile goes into the other buffer (its readers finished before the last barrier) three
-        // quarters through this step: the loads have had that long to arrive, and the end of the step is then only
-        // the barrier
+        // the next step's tile goes into the other buffer (its readers finished before the last barrier): the loads
+        // have had three quarters of a step to arrive
         __builtin_amdgcn_sched_barrier(0);
         store_ab(cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
   };
 
   load_a(0);
   if constexpr (BD) load_bd(0, bset0);
   store_ab(0);
   __syncthreads();
+  if constexpr (!BD) b_frags(b_img(0), 0, bf[0]);
+#pragma unroll
+  for (int i = 0; i < AFR - 1; ++i) af[i] = a_frag(a_img(0), i);
   for (int ks = 0; ks < nk; ks += 2) {
     step(ks, bset0, bset1);
     if (ks + 1 < nk) step(ks + 1, bset1, bset0);

@@ -447,6 +447,9 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
     st = block_sum(st, sh_f);
     lp_lse = __logf(st);
   }
+  // a row without a single comparable logit (all NaN / -inf: a broken checkpoint, an overflow upstream) has no
+  // arg-max; it yields token 0 rather than an id that the next kernels would use as an address
+  if (token < 0 || token >= V) token = 0;
   if (threadIdx.x == 0) {
     c.tokens_out[b] = token;
     if (c.logprob_out) c.logprob_out[b] = (c.forced && forced < 0) ? 0.f : (lg[token] - mx) * lp_scale - lp_lse;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
       });
       t = block_argmax(t, sh_am);
       if (threadIdx.x == 0) {
-        c.topk_ids[(size_t)b * c.top_logprobs + r] = t.i;
+        c.topk_ids[(size_t)b * c.top_logprobs + r] = t.i < V ? t.i : 0;
         c.topk_logprobs[(size_t)b * c.top_logprobs + r] = (t.v - mx) * lp_scale - lp_lse;
       }
       prev_v = t.v; prev_i = t.i;
