@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-timing", action="store_true")
+    ap.add_argument("--lora", type=int, default=0, metavar="LAYERS",
+                    help="apply rank-16 LoRA adapters (scale 10) to q_proj / v_proj of the last LAYERS blocks "
+                         "(BASELINE config 5 uses 8; SURVEY §8d)")
     ap.add_argument("--greedy", action="store_true", help="greedy decode also for the int4 workloads (A/B of the sampler)")
     ap.add_argument("--profile-kernel", default="gemv_gate_up")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (A/B experiments)")
@@ -176,6 +179,16 @@ def main():
         engine.set_option(k_, int(v_))
     t0 = time.perf_counter()
     load_synthetic(engine, cfg, args.seed, quant_bits, rank, world, dist)
+    if args.lora:
+        # A ~ U(-1/sqrt(K), 1/sqrt(K)), B ~ N(0, 0.01^2), rank 16, scale 10 (lora_init.py:68-72 defaults)
+        H, nh, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+        D = cfg.get("head_dim") or H // nh
+        g = torch.Generator().manual_seed(args.seed + 99)
+        for li in range(cfg["num_hidden_layers"] - args.lora, cfg["num_hidden_layers"]):
+            for key, n in (("self_attn.q_proj", nh * D), ("self_attn.v_proj", nkv * D)):
+                a = (torch.rand((H, 16), generator=g) * 2 - 1) / (H ** 0.5)
+                b = torch.randn((16, n), generator=g) * 0.01
+                engine.set_lora(li, key, a, b, 10.0)
     t_load = time.perf_counter() - t0
 
     rng = np.random.default_rng(args.seed + 17 * rank)                 # each rank decodes its own shard
@@ -280,7 +293,8 @@ def main():
             "data": "synthetic token ids; random-init weights N(0,0.02^2)",
             "config": {
                 "workload": f"{family} shape ({args.workload}), batch {B}/GPU, "
-                            + ("top-p 0.9 / T=1 sampling with logprobs" if quant_bits else "greedy decode") + f" from KV length {ctx}",
+                            + ("top-p 0.9 / T=1 sampling with logprobs" if quant_bits else "greedy decode") + f" from KV length {ctx}"
+                            + (f", rank-16 LoRA on q/v of the last {args.lora} layers" if args.lora else ""),
                 "batch_per_gpu": B, "global_batch": B * world, "context": ctx,
                 "kv_dtype": "bf16" if args.kv_dtype == "model" else "float32 (PagedKVCache quirk mode)",
                 "parallelism": f"dp{world} (batch-sharded replicas, no collective in the decode step)",

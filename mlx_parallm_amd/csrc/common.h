@@ -94,6 +94,25 @@ __device__ __forceinline__ float lane8_sum(float v) {
   v += __builtin_amdgcn_update_dpp(0.f, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
   return v;
 }
+// z = sum_j t[j] * B[j][col] in rank order, the loads of 8 ranks issued together (a plain loop over a run-time rank
+// waits for one L2 round trip per rank: 16 in a row per output tile)
+__device__ __forceinline__ float lora_dot(const float* tt, const float* lb_col, int ln, int rk) {
+  float z = 0.f;
+  for (int j0 = 0; j0 < rk; j0 += 8) {
+    float tv[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jj = min(j0 + j, rk - 1);
+      tv[j] = tt[jj];
+      bv[j] = lb_col[(size_t)jj * ln];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j0 + j < rk) z = fmaf(tv[j], bv[j], z);
+  }
+  return z;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
   const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));

@@ -345,7 +345,13 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       }
       scratch = e->deq_scratch;
     }
-    return launch_gemm_prefill(f.W, c, rows, e->stream, scratch);
+    MI_TRY(launch_gemm_prefill(f.W, c, rows, e->stream, scratch));
+    if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {   // y = T(y + T(scale (x A) B)) on the adapted columns
+      c.M = (int)rows;
+      MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
+      MI_TRY(launch_lora_up_add(f.W, c, e->lora_t, 128, e->stream));
+    }
+    return MI_OK;
   }
   const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
   GemvCall probe = c; probe.M = (int)std::min<size_t>(rows, 16);

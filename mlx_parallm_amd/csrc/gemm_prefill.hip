@@ -485,7 +485,8 @@ bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (!dense && !q4) return false;
   if (W.K % BK != 0 || c.ldx % 8 != 0) return false;
   if (c.epi == EPI_STORE_F32) return false;
-  if (W.lora_b[0] != nullptr || W.lora_b[1] != nullptr) return false;
+  // an adapted matrix: the caller adds the LoRA term to the stored output afterwards (launch_lora_up_add)
+  if ((W.lora_b[0] != nullptr || W.lora_b[1] != nullptr) && c.epi != EPI_STORE) return false;
   const int n = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
   return n % 16 == 0 && (c.epi != EPI_SWIGLU || c.pair_offset % 16 == 0);
 }

@@ -319,8 +319,7 @@ __global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const Sk
             const float* lb = sl ? p.lora_b1 : p.lora_b0;
             if (lb != nullptr && n >= r0 && n < r0 + ln) {
               const float* tt = p.lora_t + (size_t)m * p.lora_t_ld + sl * (p.lora_t_ld / 2);
-              float z = 0.f;
-              for (int j = 0; j < rk; ++j) z = fmaf(tt[j], lb[(size_t)j * ln + (n - r0)], z);
+              float z = lora_dot(tt, lb + (n - r0), ln, rk);
               z = (sl ? p.lora_scale_1 : p.lora_scale_0) * z;
               y = (float)(AT)(y + (float)(AT)z);
             }

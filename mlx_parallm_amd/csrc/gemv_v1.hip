@@ -290,21 +290,92 @@ __global__ __launch_bounds__(NTHR) void lora_down_kernel(GemvParams p, const flo
     if (tid == 0) rs_sh = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
     __syncthreads();
   }
-  for (int j = 0; j < rk; ++j) {
-    float s = 0.f;
-    for (int k = tid; k < p.K; k += NTHR) {
-      float v = to_f32(x[k]);
-      if (p.pro == PRO_NORM) {
-        AT xn = store_act<AT>(v * rs_sh, p.rnd);
-        v = to_f32(store_act<AT>(to_f32(xn) * to_f32(((const AT*)p.norm_w)[k]), p.rnd));
+  // 16 columns of A at a time: one pass over x per 16 ranks instead of one per rank (the per-thread order of the
+  // k sum, the wave reduction and the order of the four wave partials are those of a single-column pass, so t is
+  // unchanged bit for bit)
+  __shared__ float red16[4][16];
+  for (int j0 = 0; j0 < rk; j0 += 16) {
+    float s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = 0.f;
+    // four k per trip with all their loads issued before the first fma (a thread's 20 k at K = 5120 were 20
+    // dependent L2 round trips: 37 us per launch); the fma order per column is still k ascending
+    const bool vec = (rk % 4 == 0) && (j0 + 16 <= rk);
+    for (int k0 = tid; k0 < p.K; k0 += 4 * NTHR) {
+      float v[4], nw[4];
+      float4 a4[4][4];
+      float a1[4][16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * NTHR, kc = k < p.K ? k : tid;
+        v[u] = to_f32(x[kc]);
+        nw[u] = p.pro == PRO_NORM ? to_f32(((const AT*)p.norm_w)[kc]) : 1.0f;
+        const float* ar = A + (size_t)kc * rk + j0;
+        if (vec) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a4[u][q] = ((const float4*)ar)[q];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) a1[u][j] = ar[j0 + j < rk ? j : 0];
+        }
       }
-      s = fmaf(v, A[(size_t)k * rk + j], s);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * NTHR;
+        if (k >= p.K) break;
+        float vv = v[u];
+        if (p.pro == PRO_NORM) {
+          AT xn = store_act<AT>(vv * rs_sh, p.rnd);
+          vv = to_f32(store_act<AT>(to_f32(xn) * nw[u], p.rnd));
+        }
+        if (vec) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            s[4 * q + 0] = fmaf(vv, a4[u][q].x, s[4 * q + 0]);
+            s[4 * q + 1] = fmaf(vv, a4[u][q].y, s[4 * q + 1]);
+            s[4 * q + 2] = fmaf(vv, a4[u][q].z, s[4 * q + 2]);
+            s[4 * q + 3] = fmaf(vv, a4[u][q].w, s[4 * q + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j0 + j < rk) s[j] = fmaf(vv, a1[u][j], s[j]);
+        }
+      }
     }
-    s = wave_sum(s);
     __syncthreads();
-    if (lane == 0) red[wave] = s;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float w = wave_sum(s[j]);
+      if (lane == 0) red16[wave][j] = w;
+    }
     __syncthreads();
-    if (tid == 0) t[(size_t)m * t_ld + slot * (t_ld / 2) + j] = round_rt(red[0] + red[1] + red[2] + red[3], p.lora_rnd);
+    if (tid < 16 && j0 + tid < rk)
+      t[(size_t)m * t_ld + slot * (t_ld / 2) + j0 + tid] =
+          round_rt(red16[0][tid] + red16[1][tid] + red16[2][tid] + red16[3][tid], p.lora_rnd);
+  }
+}
+
+// y[m][n] = T(y[m][n] + T(scale * sum_j t[m][slot][j] * B[j][n - row0]))  for the adapted column ranges: the LoRA term
+// of the GEMV epilogues, applied after a tile GEMM has stored y = T(x W^T) (prefill)
+template <typename AT>
+__global__ __launch_bounds__(256) void lora_up_add_kernel(GemvParams p, const float* t, int t_ld, AT* y, int ldy) {
+  const int m = blockIdx.x;
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const float* lb = sl ? p.lora_b1 : p.lora_b0;
+    if (lb == nullptr) continue;
+    const int r0 = sl ? p.lora_row0_1 : p.lora_row0_0;
+    const int ln = sl ? p.lora_n_1 : p.lora_n_0;
+    const int rk = sl ? p.lora_rank_1 : p.lora_rank_0;
+    const float sc = sl ? p.lora_scale_1 : p.lora_scale_0;
+    const float* tt = t + (size_t)m * t_ld + sl * (t_ld / 2);
+    for (int n = threadIdx.x; n < ln; n += 256) {
+      float z = lora_dot(tt, lb + n, ln, rk);
+      z = sc * z;
+      AT* o = y + (size_t)m * ldy + r0 + n;
+      *o = (AT)((float)*o + (float)(AT)z);
+    }
   }
 }
 
@@ -381,6 +452,20 @@ int launch_lora_down(const LinearW& W, const GemvCall& c, float* t, int t_ld, hi
     case MI_BF16: hipLaunchKernelGGL(lora_down_kernel<bf16>, grid, dim3(NTHR), 0, st, p, W.lora_a[0], W.lora_a[1], t, t_ld); break;
     case MI_F16: hipLaunchKernelGGL(lora_down_kernel<f16>, grid, dim3(NTHR), 0, st, p, W.lora_a[0], W.lora_a[1], t, t_ld); break;
     default: return fail(MI_ERR_INVALID, "lora_down: bad activation dtype");
+  }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// c.out ([rows][ldo], EPI_STORE) += the LoRA term, rows = c.M, from t = launch_lora_down's output
+int launch_lora_up_add(const LinearW& W, const GemvCall& c, const float* t, int t_ld, hipStream_t st) {
+  if (c.epi != EPI_STORE) return fail(MI_ERR_UNSUPPORTED, "lora_up_add: plain store epilogue only");
+  GemvParams p = make_params(W, c);
+  const dim3 grid(c.M), block(256);
+  switch (c.act) {
+    case MI_BF16: hipLaunchKernelGGL(lora_up_add_kernel<bf16>, grid, block, 0, st, p, t, t_ld, (bf16*)c.out, c.ldo); break;
+    case MI_F16: hipLaunchKernelGGL(lora_up_add_kernel<f16>, grid, block, 0, st, p, t, t_ld, (f16*)c.out, c.ldo); break;
+    default: return fail(MI_ERR_UNSUPPORTED, "lora_up_add: 16-bit activations only");
   }
   MI_HIP(hipGetLastError());
   return MI_OK;

@@ -108,6 +108,8 @@ __host__ __device__ inline int tiled_q4_scale_off(size_t row, int k) {  // + 64 
 }
 // t[m][slot][j] = round(sum_k x[m][k] A[k][j]) for the adapted ranges of W (same prologue as the gemv)
 int launch_lora_down(const LinearW& W, const GemvCall& c, float* t, int t_ld, hipStream_t st);
+// the LoRA term of the GEMV epilogues applied to an already stored c.out (EPI_STORE, c.M rows): after a tile GEMM
+int launch_lora_up_add(const LinearW& W, const GemvCall& c, const float* t, int t_ld, hipStream_t st);
 
 struct EmbedCall {
   const int32_t* tokens;  // device [rows]

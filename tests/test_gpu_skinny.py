@@ -180,8 +180,15 @@ def test_large_batch_decode_with_lora(tiny_dirs, tmp_path):
     toks = _prompts(cfg, B, 6, seed=3)
     kv = model.engine.new_kv(B, capacity=16, kv_dtype="model")
     cache, bcache = ref.make_cache(B, paged=False), base.make_cache(B, paged=False)
-    model.engine.forward(toks, kv)
-    nxt = np.argmax(ref(toks, cache=cache)[:, -1], axis=-1)[:, None]
+    # the prefill is 144 rows: the tile GEMM + the LoRA term added to its stored output (launch_lora_up_add)
+    got0 = model.engine.forward(toks, kv)
+    want0 = ref(toks, cache=cache)[:, -1]
+    assert np.abs(got0 - want0).max() <= 0.08, np.abs(got0 - want0).max()
+    model.engine.set_option("prefill_gemm", 0)                  # ... and the same through the 16-row launches
+    kv0 = model.engine.new_kv(B, capacity=16, kv_dtype="model")
+    assert np.abs(model.engine.forward(toks, kv0) - got0).max() <= 0.08
+    model.engine.set_option("prefill_gemm", 1)
+    nxt = np.argmax(want0, axis=-1)[:, None]
     base(toks, cache=bcache)
     got = model.engine.forward(nxt.astype(np.int32), kv)
     want = ref(nxt, cache=cache)[:, -1]
