@@ -124,7 +124,8 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="mistral-7b-bf16",
-                    choices=["mistral-7b-bf16", "mistral-7b-int4", "qwen3-14b-bf16", "qwen3-14b-int4", "tiny-bf16"])
+                    choices=["mistral-7b-bf16", "mistral-7b-int4", "mistral-7b-int8", "qwen3-14b-bf16", "qwen3-14b-int4",
+                             "qwen3-14b-int8", "tiny-bf16"])
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--kv-dtype", default="model", choices=["model", "float32"])
@@ -167,7 +168,7 @@ def main():
     from mlx_parallm_amd.engine import Engine, SampleArgs
 
     family, prec = args.workload.rsplit("-", 1)
-    quant_bits = 4 if prec == "int4" else 0
+    quant_bits = {"int4": 4, "int8": 8}.get(prec, 0)
     cfg = dict(SHAPES[family])
     if quant_bits:
         cfg["quantization"] = {"group_size": 64, "bits": quant_bits}
@@ -289,7 +290,7 @@ def main():
         out = {
             "metric": "decode_tokens_per_sec", "value": round(value, 2), "unit": "tokens/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not quant_bits else "int4-g64 weights, bf16 activations",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not quant_bits else f"int{quant_bits}-g64 weights, bf16 activations",
             "data": "synthetic token ids; random-init weights N(0,0.02^2)",
             "config": {
                 "workload": f"{family} shape ({args.workload}), batch {B}/GPU, "

@@ -482,7 +482,8 @@ bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
   const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 128 == 0;                       // through a [hi | lo] 16-bit copy (launch_dequant_q4_hilo)
-  if (!dense && !q4) return false;
+  const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64;
+  if (!dense && !q4 && !q8) return false;
   if (W.K % BK != 0 || c.ldx % 8 != 0) return false;
   if (c.epi == EPI_STORE_F32) return false;
   // an adapted matrix: the caller adds the LoRA term to the stored output afterwards (launch_lora_up_add)

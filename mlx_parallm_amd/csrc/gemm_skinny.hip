@@ -42,6 +42,18 @@ using namespace gemv;
 constexpr int SK_NW = 8;      // waves (= tiles) per workgroup
 constexpr int SK_KC = 256;    // k per activation chunk
 
+// 8 int8 codes (two packed dwords) -> 8 16-bit floats: 0..255 are exact in bf16 and f16
+template <typename T>
+__device__ __forceinline__ u32x4 unpack_q8(uint32_t lo, uint32_t hi) {
+  T e[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[j] = (T)(float)((lo >> (8 * j)) & 255u);
+    e[4 + j] = (T)(float)((hi >> (8 * j)) & 255u);
+  }
+  return *(const u32x4*)e;
+}
+
 struct SkinnyParams {
   const void* x; int ldx; int M;
   const void* w; int N, K;
@@ -57,15 +69,17 @@ struct SkinnyParams {
   int lora_row0_1, lora_n_1, lora_rank_1; float lora_scale_1;
 };
 
-template <typename AT, bool Q4, int MT, bool SWIGLU>
-__global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
+// QB: 0 = dense 16-bit weights, 4 / 8 = MLX-affine int4 / int8 codes (group 64)
+template <typename AT, int QB, int MT, bool SWIGLU>
+__global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
+  constexpr bool Q4 = QB == 4, Q8 = QB == 8, QUANT = QB != 0;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
   constexpr int UK = (Q4 ? 4 : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
-  constexpr int UPC = Q4 ? 2 : 8;           // loads per chunk (a load covers 128 / 32 k)
+  constexpr int UPC = Q4 ? 2 : Q8 ? 4 : 8;  // loads per chunk (a load covers 128 / 64 / 32 k)
   constexpr int CPI = UK > UPC ? UK / UPC : 1;   // chunks per trip of the loop body (the slot ring has UK entries)
-  constexpr int UB = Q4 ? 1152 : 1024;      // bytes of one tile-major block
+  constexpr int UB = Q4 ? 1152 : Q8 ? 1088 : 1024;   // bytes of one tile-major block
   constexpr int FRAG = MB * 512;            // fragment bytes per buffer (MB x 256 x 2)
-  constexpr int BUF = FRAG + (Q4 ? MB * 16 : 0);   // + sum(x) per (64-group, row) for the int4 bias term
+  constexpr int BUF = FRAG + (QUANT ? MB * 16 : 0);   // + sum(x) per (64-group, row) for the quantisation bias term
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int last_sh;
 
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const Sk
   for (int a = 0; a < NA; ++a) wb[a] = (const char*)p.w + (size_t)(tile + a * (p.pair_offset >> 4)) * nunits * UB;
 
   u32x4 wr[NA][UK];
-  uint32_t sr[NA][Q4 ? UK : 1], br[NA][Q4 ? UK : 1];
+  uint32_t sr[NA][QUANT ? UK : 1], br[NA][QUANT ? UK : 1];
   f32x4 acc[NA][MT];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -100,6 +114,9 @@ __global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const Sk
       if constexpr (Q4) {
         sr[a][slot] = *(const uint32_t*)(blk + 1024 + c16 * 4);
         br[a][slot] = *(const uint32_t*)(blk + 1088 + c16 * 4);
+      } else if constexpr (Q8) {
+        sr[a][slot] = *(const uint16_t*)(blk + 1024 + c16 * 2);
+        br[a][slot] = *(const uint16_t*)(blk + 1056 + c16 * 2);
       }
     }
   };
@@ -120,6 +137,11 @@ __global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const Sk
       const int kb = k8l >> 4, sg = (k8l >> 3) & 1, t = k8lo & 1, e = k8lo - t;
       const int gg = (e == 0) ? 0 : (e == 4) ? 1 : (e == 2) ? 2 : 3;
       P = ((kb * 2 + sg) * 2 + t) * 4 + gg;
+    } else if constexpr (Q8) {
+      // a lane of the int8 block holds 16 consecutive k: its first 8 feed the first MFMA of the 64-block, the
+      // other 8 the second (the MFMA k index is a free labelling) -> piece (g, t) of the block = k 16 g + 8 t
+      const int kb = k8l >> 3, gg = (k8lo >> 1), t = k8lo & 1;
+      P = (kb * 2 + t) * 4 + gg;
     }
     woff[i] = (P * MB + (m ^ ((P & 7) << 1))) * 16;
     sxoff[i] = FRAG + ((k8l >> 3) * MB + m) * 4;
@@ -140,16 +162,18 @@ __global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const Sk
     for (int i = 0; i < MT; ++i) {
       const bool ok = xm[i] && (c * SK_KC + xk[i] < p.K);
       u32x4 v = ok ? xr[i] : u32x4{0u, 0u, 0u, 0u};
-      if constexpr (Q4) {
+      if constexpr (QUANT) {
         AT* e = (AT*)&v;
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += (float)e[j];
-        AT t2[8];
+        if constexpr (Q4) {                    // nibble order inside the piece (gemv_phase.h)
+          AT t2[8];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) { t2[2 * qd] = e[qd]; t2[2 * qd + 1] = e[qd + 4]; }
+          for (int qd = 0; qd < 4; ++qd) { t2[2 * qd] = e[qd]; t2[2 * qd + 1] = e[qd + 4]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = t2[j];
+          for (int j = 0; j < 8; ++j) e[j] = t2[j];
+        }
         sum = lane8_sum(sum);
         if ((tid & 7) == 0) *(float*)(buf + sxoff[i]) = sum;
       }
@@ -163,7 +187,36 @@ __global__ __launch_bounds__(SK_NW * 64, Q4 ? 2 : 4) void skinny_kernel(const Sk
   for (int par = 0; par < 2; ++par) lane_off[par] = (g * MB + (c16 ^ ((par * 4 + g) << 1))) * 16;
 
   auto mfma_unit = [&](int slot, int i, const unsigned char* cur) {
-    if constexpr (!Q4) {
+    if constexpr (Q8) {
+      // unit i = the i-th 64-block (= quantisation group) of the chunk: y += s * sum(q x) + b * sum(x)
+      u32x4 wq[NA][2];
+      float sc[NA], bb[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const u32x4 v = wr[a][slot];
+        wq[a][0] = unpack_q8<AT>(v.x, v.y);
+        wq[a][1] = unpack_q8<AT>(v.z, v.w);
+        sc[a] = (float)__builtin_bit_cast(AT, (unsigned short)sr[a][slot]);
+        bb[a] = (float)__builtin_bit_cast(AT, (unsigned short)br[a][slot]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int pb = (i * 2) * 4 * MB + mt * 16;
+        const u32x4 af0 = *(const u32x4*)(cur + lane_off[0] + pb * 16);
+        const u32x4 af1 = *(const u32x4*)(cur + lane_off[1] + (pb + 4 * MB) * 16);
+        const f32x4 sxv = *(const f32x4*)(cur + FRAG + (i * MB + mt * 16 + g * 4) * 4);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          d = mfma16<AT>(af0, wq[a][0], d);
+          d = mfma16<AT>(af1, wq[a][1], d);
+          acc[a][mt].x = fmaf(sc[a], d.x, fmaf(bb[a], sxv.x, acc[a][mt].x));
+          acc[a][mt].y = fmaf(sc[a], d.y, fmaf(bb[a], sxv.y, acc[a][mt].y));
+          acc[a][mt].z = fmaf(sc[a], d.z, fmaf(bb[a], sxv.z, acc[a][mt].z));
+          acc[a][mt].w = fmaf(sc[a], d.w, fmaf(bb[a], sxv.w, acc[a][mt].w));
+        }
+      }
+    } else if constexpr (!Q4) {
       u32x4 af[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) af[mt] = *(const u32x4*)(cur + lane_off[i & 1] + (i * 4 * MB + mt * 16) * 16);
@@ -350,7 +403,7 @@ SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
   pl.ngroups = (pl.ntiles + SK_NW - 1) / SK_NW;
   pl.nchunks = (W.K + SK_KC - 1) / SK_KC;
   const double cus = gemv_cu_count(), bw = 6.3e12, r_max = 40e9;
-  const double bpe = wk_is_quant(W.wk) ? 0.5625 : 2.0;
+  const double bpe = (W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16) ? 1.0625 : wk_is_quant(W.wk) ? 0.5625 : 2.0;
   const double unit_p = 2.0 * SK_NW * 16 * pl.na * pl.mt * 16 * 4;          // written + read
   double best = 0.0;
   pl.ksplit = 1;
@@ -365,10 +418,10 @@ SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
   return pl;
 }
 
-template <typename AT, bool Q4, int MT, bool SWIGLU>
+template <typename AT, int QB, int MT, bool SWIGLU>
 int launch_k(const SkinnyParams& p, int grid, hipStream_t st) {
-  auto kern = skinny_kernel<AT, Q4, MT, SWIGLU>;
-  const size_t lds = 2 * ((size_t)16 * MT * 512 + (Q4 ? 16 * MT * 16 : 0));
+  auto kern = skinny_kernel<AT, QB, MT, SWIGLU>;
+  const size_t lds = 2 * ((size_t)16 * MT * 512 + (QB ? 16 * MT * 16 : 0));
   static bool attr_done = false;
   if (!attr_done) {
     MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 512 + 64 * 16)));
@@ -379,31 +432,35 @@ int launch_k(const SkinnyParams& p, int grid, hipStream_t st) {
   return MI_OK;
 }
 
-template <typename AT, bool Q4, bool SWIGLU>
+template <typename AT, int QB, bool SWIGLU>
 int launch_mt(const SkinnyParams& p, int mt, int grid, hipStream_t st) {
   switch (mt) {
-    case 2: return launch_k<AT, Q4, 2, SWIGLU>(p, grid, st);
-    case 3: return launch_k<AT, Q4, 3, SWIGLU>(p, grid, st);
-    case 4: return launch_k<AT, Q4, 4, SWIGLU>(p, grid, st);
+    case 1: if constexpr (QB == 8) return launch_k<AT, QB, 1, SWIGLU>(p, grid, st); else break;   // int8: every decode step
+    case 2: return launch_k<AT, QB, 2, SWIGLU>(p, grid, st);
+    case 3: return launch_k<AT, QB, 3, SWIGLU>(p, grid, st);
+    case 4: return launch_k<AT, QB, 4, SWIGLU>(p, grid, st);
   }
-  return fail(MI_ERR_INVALID, "gemm_skinny: 17..64 rows");
+  return fail(MI_ERR_INVALID, "gemm_skinny: 17..64 rows (int8: 1..64)");
 }
 
 template <typename AT>
-int launch_at(const SkinnyParams& p, bool q4, bool swiglu, int mt, int grid, hipStream_t st) {
-  if (q4) return swiglu ? launch_mt<AT, true, true>(p, mt, grid, st) : launch_mt<AT, true, false>(p, mt, grid, st);
-  return swiglu ? launch_mt<AT, false, true>(p, mt, grid, st) : launch_mt<AT, false, false>(p, mt, grid, st);
+int launch_at(const SkinnyParams& p, int qb, bool swiglu, int mt, int grid, hipStream_t st) {
+  if (qb == 4) return swiglu ? launch_mt<AT, 4, true>(p, mt, grid, st) : launch_mt<AT, 4, false>(p, mt, grid, st);
+  if (qb == 8) return swiglu ? launch_mt<AT, 8, true>(p, mt, grid, st) : launch_mt<AT, 8, false>(p, mt, grid, st);
+  return swiglu ? launch_mt<AT, 0, true>(p, mt, grid, st) : launch_mt<AT, 0, false>(p, mt, grid, st);
 }
 
 }  // namespace
 
 bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
-  if (rows <= 16 || rows > 64) return false;
+  const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64 &&
+                  W.K % 64 == 0;                         // int8 has no M <= 16 kernel of its own: every decode step runs here
+  if (rows < 1 || rows > 64 || (rows <= 16 && !q8)) return false;
   const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
   const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 128 == 0;
-  if (!dense && !q4) return false;
+  if (!dense && !q4 && !q8) return false;
   if (W.K % 32 != 0 || c.ldx % 8 != 0) return false;
   const int n = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
   return n % 16 == 0;
@@ -431,9 +488,10 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   p.lora_b0 = W.lora_b[0]; p.lora_b1 = W.lora_b[1];
   p.lora_row0_0 = W.lora_row0[0]; p.lora_n_0 = W.lora_n[0]; p.lora_rank_0 = W.lora_rank[0]; p.lora_scale_0 = W.lora_scale[0];
   p.lora_row0_1 = W.lora_row0[1]; p.lora_n_1 = W.lora_n[1]; p.lora_rank_1 = W.lora_rank[1]; p.lora_scale_1 = W.lora_scale[1];
-  const bool q4 = wk_is_quant(W.wk), sw = c.epi == EPI_SWIGLU;
+  const int qb = (W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16) ? 8 : wk_is_quant(W.wk) ? 4 : 0;
+  const bool sw = c.epi == EPI_SWIGLU;
   const int grid = pl.ngroups * pl.ksplit;
-  return c.act == MI_BF16 ? launch_at<bf16>(p, q4, sw, pl.mt, grid, st) : launch_at<f16>(p, q4, sw, pl.mt, grid, st);
+  return c.act == MI_BF16 ? launch_at<bf16>(p, qb, sw, pl.mt, grid, st) : launch_at<f16>(p, qb, sw, pl.mt, grid, st);
 }
 
 int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ksplit; }

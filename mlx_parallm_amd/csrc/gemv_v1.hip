@@ -76,6 +76,11 @@ __device__ __forceinline__ void load8(const GemvParams& p, int row, int kb, floa
       const int so = tiled_q4_scale_off(row, kb);
       if constexpr (SDT == 1) { s = (float)*(const bf16*)(blk + so); b = (float)*(const bf16*)(blk + so + 64); }
       else { s = (float)*(const f16*)(blk + so); b = (float)*(const f16*)(blk + so + 64); }
+    } else if (BITS == 8 && SDT != 0 && p.layout) {  // tile-major int8
+      blk = (const char*)p.w + tiled_block_q8(row, kb, p.K);
+      const int so = tiled_q8_scale_off(row);
+      if constexpr (SDT == 1) { s = (float)*(const bf16*)(blk + so); b = (float)*(const bf16*)(blk + so + 32); }
+      else { s = (float)*(const f16*)(blk + so); b = (float)*(const f16*)(blk + so + 32); }
     } else if constexpr (SDT == 0) { s = ((const float*)p.scales)[gi]; b = ((const float*)p.biases)[gi]; }
     else if constexpr (SDT == 1) { s = (float)((const bf16*)p.scales)[gi]; b = (float)((const bf16*)p.biases)[gi]; }
     else { s = (float)((const f16*)p.scales)[gi]; b = (float)((const f16*)p.biases)[gi]; }
@@ -86,7 +91,8 @@ __device__ __forceinline__ void load8(const GemvParams& p, int row, int kb, floa
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = mul_add_unfused((float)((v >> (4 * j)) & 15u), s, b);
     } else {
-      const uint32_t* base = (const uint32_t*)p.w + (size_t)row * (p.K / 4) + kb / 4;
+      const uint32_t* base = blk ? (const uint32_t*)(blk + tiled_q8_code_off(row, kb))
+                                 : (const uint32_t*)p.w + (size_t)row * (p.K / 4) + kb / 4;
       u32x2 v = __builtin_nontemporal_load((const u32x2*)base);
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = mul_add_unfused((float)((v.x >> (8 * j)) & 255u), s, b);

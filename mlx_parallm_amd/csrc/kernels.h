@@ -106,6 +106,15 @@ __host__ __device__ inline int tiled_q4_code_off(size_t row, int k) {   // withi
 __host__ __device__ inline int tiled_q4_scale_off(size_t row, int k) {  // + 64 for the bias
   return 1024 + (int)(row & 15) * 4 + ((k >> 6) & 1) * 2;
 }
+// tile-major int8 (group 64): block (row tile, k / 64) of 1088 bytes = [1024 codes: lane l = g*16 + r owns the 16
+// codes W[16i + r][64j + 16g .. +16)] [32 B scales: row r -> one 16-bit value] [32 B biases]
+__host__ __device__ inline size_t tiled_block_q8(size_t row, int k, int K) {
+  return ((row >> 4) * (size_t)(K / 64) + (size_t)(k >> 6)) * 1088;
+}
+__host__ __device__ inline int tiled_q8_code_off(size_t row, int k) {   // within the block, bytes
+  return (((k >> 4) & 3) * 16 + (int)(row & 15)) * 16 + (k & 15);
+}
+__host__ __device__ inline int tiled_q8_scale_off(size_t row) { return 1024 + (int)(row & 15) * 2; }   // + 32 for the bias
 // t[m][slot][j] = round(sum_k x[m][k] A[k][j]) for the adapted ranges of W (same prologue as the gemv)
 int launch_lora_down(const LinearW& W, const GemvCall& c, float* t, int t_ld, hipStream_t st);
 // the LoRA term of the GEMV epilogues applied to an already stored c.out (EPI_STORE, c.M rows): after a tile GEMM

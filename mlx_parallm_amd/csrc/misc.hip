@@ -37,6 +37,12 @@ __global__ __launch_bounds__(256) void embed_kernel(LinearW W, EmbedCall c) {
         if constexpr (SDT == 1) { s = (float)*(const bf16*)(blk + so); b = (float)*(const bf16*)(blk + so + 64); }
         else { s = (float)*(const f16*)(blk + so); b = (float)*(const f16*)(blk + so + 64); }
         word = *(const uint32_t*)(blk + tiled_q4_code_off(tok, k8));
+      } else if (BITS == 8 && SDT != 0 && W.layout) {   // tile-major int8
+        const char* blk = (const char*)W.w + tiled_block_q8(tok, k, W.K);
+        const int so = tiled_q8_scale_off(tok);
+        if constexpr (SDT == 1) { s = (float)*(const bf16*)(blk + so); b = (float)*(const bf16*)(blk + so + 32); }
+        else { s = (float)*(const f16*)(blk + so); b = (float)*(const f16*)(blk + so + 32); }
+        word = *(const uint32_t*)(blk + tiled_q8_code_off(tok, k & ~3));
       } else {
       if constexpr (SDT == 0) { s = ((const float*)W.scales)[gi]; b = ((const float*)W.biases)[gi]; }
       else if constexpr (SDT == 1) { s = (float)((const bf16*)W.scales)[gi]; b = (float)((const bf16*)W.biases)[gi]; }

@@ -13,6 +13,9 @@
 //                 [0,1024)    codes: lane l = g*16 + r owns the 4 packed dwords 4g..4g+3 of row r's 16
 //                 [1024,1088) scales: row r -> 2 x 16-bit (quantisation groups 2j, 2j+1)
 //                 [1088,1152) biases: same shape.
+//   int8 (g64):   block (i, j = k/64) at ((i * K/64 + j) * 1088) bytes:
+//                 [0,1024)    codes: lane l = g*16 + r owns the 16 codes W[16i+r][64j + 16g .. +16) (4 packed dwords)
+//                 [1024,1056) scales: row r -> one 16-bit value;  [1056,1088) biases.
 #include "kernels.h"
 
 namespace mi {
@@ -50,6 +53,24 @@ __global__ void repack_q4_kernel(const uint32_t* codes, const uint16_t* scales, 
   }
 }
 
+__global__ void repack_q8_kernel(const uint32_t* codes, const uint16_t* scales, const uint16_t* biases, uint8_t* dst,
+                                 int N, int K) {
+  const int nb = K / 64;
+  const size_t blocks = (size_t)(N / 16) * nb;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < blocks * 64; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = idx >> 6;
+    const int lane = (int)(idx & 63), r = lane & 15, g = lane >> 4;
+    const size_t i = blk / nb, j = blk % nb;
+    const size_t row = i * 16 + r;
+    uint8_t* base = dst + blk * 1088;
+    *(u32x4*)(base + lane * 16) = *(const u32x4*)(codes + row * (K / 4) + j * 16 + g * 4);
+    if (g == 0) {
+      *(uint16_t*)(base + 1024 + r * 2) = scales[row * (K / 64) + j];
+      *(uint16_t*)(base + 1056 + r * 2) = biases[row * (K / 64) + j];
+    }
+  }
+}
+
 // int4 tile-major -> dense 16-bit tile-major [hi | lo] with K' = 2K (the prefill GEMM's operand for quantised
 // weights): w = scale * q + bias in float32 (as the oracle dequantises), hi = T(w), lo = T(w - hi), so that
 // x . hi + x . lo reproduces x . w to 2^-17 relative -- below the accumulation-order noise of any fp32 GEMM.
@@ -82,16 +103,50 @@ __global__ void dequant_q4_hilo_kernel(const uint8_t* src, T* dst, int N, int K)
   }
 }
 
+// the same for tile-major int8
+template <typename T>
+__global__ void dequant_q8_hilo_kernel(const uint8_t* src, T* dst, int N, int K) {
+  const size_t pieces = (size_t)N * (K / 8);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pieces; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = idx >> 6;
+    const int lane = (int)(idx & 63), r = lane & 15, g = lane >> 4;
+    const size_t i = blk / (K / 32), j = blk % (K / 32);
+    const size_t row = i * 16 + r;
+    const int k = (int)j * 32 + g * 8;
+    const uint8_t* qb = src + tiled_block_q8(row, k, K);
+    const uint8_t* cp = qb + tiled_q8_code_off(row, k);
+    const uint32_t c0 = *(const uint32_t*)cp, c1 = *(const uint32_t*)(cp + 4);
+    const float s = (float)*(const T*)(qb + tiled_q8_scale_off(row));
+    const float b = (float)*(const T*)(qb + tiled_q8_scale_off(row) + 32);
+    T hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t q = ((e < 4 ? c0 : c1) >> (8 * (e & 3))) & 255u;
+      const float w = mul_add_unfused(s, (float)q, b);
+      hi[e] = (T)w;
+      lo[e] = (T)(w - (float)hi[e]);
+    }
+    const size_t kb2 = (size_t)(2 * K) / 32;
+    T* dh = dst + ((i * kb2 + j) * 64 + lane) * 8;
+    T* dl = dst + ((i * kb2 + (size_t)(K / 32) + j) * 64 + lane) * 8;
+    *(u32x4*)dh = *(const u32x4*)hi;
+    *(u32x4*)dl = *(const u32x4*)lo;
+  }
+}
+
 }  // namespace
 
 size_t dequant_hilo_bytes(int N, int K) { return (size_t)N * K * 2 * 2; }
 
 int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st) {
-  if (src.layout != 1 || (src.wk != WK_Q4_BF16 && src.wk != WK_Q4_F16) || src.group != 64 || src.K % 128 != 0 || src.N % 16 != 0)
-    return fail(MI_ERR_UNSUPPORTED, "dequant: tile-major int4 (group 64) matrices only");
+  const bool q4 = src.wk == WK_Q4_BF16 || src.wk == WK_Q4_F16, q8 = src.wk == WK_Q8_BF16 || src.wk == WK_Q8_F16;
+  if (src.layout != 1 || (!q4 && !q8) || src.group != 64 || src.K % (q4 ? 128 : 64) != 0 || src.N % 16 != 0)
+    return fail(MI_ERR_UNSUPPORTED, "dequant: tile-major int4 / int8 (group 64) matrices only");
   const dim3 grid(4096), block(256);
   if (src.wk == WK_Q4_BF16) hipLaunchKernelGGL(dequant_q4_hilo_kernel<bf16>, grid, block, 0, st, (const uint8_t*)src.w, (bf16*)dst, src.N, src.K);
-  else hipLaunchKernelGGL(dequant_q4_hilo_kernel<f16>, grid, block, 0, st, (const uint8_t*)src.w, (f16*)dst, src.N, src.K);
+  else if (src.wk == WK_Q4_F16) hipLaunchKernelGGL(dequant_q4_hilo_kernel<f16>, grid, block, 0, st, (const uint8_t*)src.w, (f16*)dst, src.N, src.K);
+  else if (src.wk == WK_Q8_BF16) hipLaunchKernelGGL(dequant_q8_hilo_kernel<bf16>, grid, block, 0, st, (const uint8_t*)src.w, (bf16*)dst, src.N, src.K);
+  else hipLaunchKernelGGL(dequant_q8_hilo_kernel<f16>, grid, block, 0, st, (const uint8_t*)src.w, (f16*)dst, src.N, src.K);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -100,11 +155,13 @@ bool tiled_supported(int wk, int N, int K, int group) {
   if (N % 16 != 0) return false;
   if (wk == WK_BF16 || wk == WK_F16) return K % 32 == 0;
   if (wk == WK_Q4_BF16 || wk == WK_Q4_F16) return group == 64 && K % 128 == 0;
+  if (wk == WK_Q8_BF16 || wk == WK_Q8_F16) return group == 64 && K % 64 == 0;
   return false;
 }
 
 size_t tiled_bytes(int wk, int N, int K) {
   if (wk == WK_BF16 || wk == WK_F16) return (size_t)N * K * 2;
+  if (wk == WK_Q8_BF16 || wk == WK_Q8_F16) return (size_t)(N / 16) * (K / 64) * 1088;
   return (size_t)(N / 16) * (K / 128) * 1152;
 }
 
@@ -114,6 +171,9 @@ int launch_repack_tiled(const LinearW& src, void* dst, hipStream_t st) {
   const dim3 grid(2048), block(256);
   if (src.wk == WK_BF16 || src.wk == WK_F16)
     hipLaunchKernelGGL(repack_dense16_kernel, grid, block, 0, st, (const uint16_t*)src.w, (uint16_t*)dst, src.N, src.K);
+  else if (src.wk == WK_Q8_BF16 || src.wk == WK_Q8_F16)
+    hipLaunchKernelGGL(repack_q8_kernel, grid, block, 0, st, (const uint32_t*)src.w, (const uint16_t*)src.scales,
+                       (const uint16_t*)src.biases, (uint8_t*)dst, src.N, src.K);
   else
     hipLaunchKernelGGL(repack_q4_kernel, grid, block, 0, st, (const uint32_t*)src.w, (const uint16_t*)src.scales,
                        (const uint16_t*)src.biases, (uint8_t*)dst, src.N, src.K);

@@ -26,15 +26,17 @@ def _weight(kind, N, K):
         assert to_tiled(ol, keep)
         return ol, w, keep
     sdt = {"bf16": "bfloat16", "f16": "float16"}[kind.split("_")[1]]
+    bits = 8 if kind.startswith("q8") else 4
     w = RNG.standard_normal((N, K)).astype(np.float32) * 0.05
-    packed, scales, biases = ref_quant.quantize(round_to(w, sdt), 64, 4, sdt)
+    packed, scales, biases = ref_quant.quantize(round_to(w, sdt), 64, bits, sdt)
     pd, sd, bd = dev_u32(packed), dev(scales, sdt), dev(biases, sdt)
     ol, keep = op_linear(kind, N, K, pd, sd, bd), [pd, sd, bd]
     assert to_tiled(ol, keep)
-    return ol, ref_quant.dequantize(packed, scales, biases, 64, 4), keep
+    return ol, ref_quant.dequantize(packed, scales, biases, 64, bits), keep
 
 
-KINDS = [("bfloat16", "bf16"), ("float16", "f16"), ("bfloat16", "q4_bf16"), ("float16", "q4_f16")]
+KINDS = [("bfloat16", "bf16"), ("float16", "f16"), ("bfloat16", "q4_bf16"), ("float16", "q4_f16"),
+         ("bfloat16", "q8_bf16"), ("float16", "q8_f16")]
 
 
 @pytest.mark.parametrize("act,kind", KINDS)
@@ -196,3 +198,21 @@ def test_large_batch_decode_with_lora(tiny_dirs, tmp_path):
     assert np.abs(want - plain).max() > 0.5                     # the adapter really changes the logits
     assert np.abs(got - want).max() <= 0.08, np.abs(got - want).max()
     model.engine.close()
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "q8_bf16"), ("float16", "q8_f16")])
+@pytest.mark.parametrize("M,N,K,ksplit", [(1, 80, 128, 1), (8, 256, 4608, 0), (13, 144, 384, 3), (16, 1040, 1024, 2)])
+def test_int8_decode_rows(act, kind, M, N, K, ksplit):
+    """int8 weights have no M <= 16 kernel of their own: every decode step runs through the 16-row instantiation."""
+    ol, wdense, keep = _weight(kind, N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    xd = dev(x, act)
+    out = torch.full((M + 1, N), 7.0, dtype=xd.dtype, device="cuda")
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE, out=out, ldo=N, ksplit=ksplit)
+    got = host(out)
+    assert np.all(got[M:] == 7.0)
+    _assert_close(got[:M], round_to(matmul_nt(x, wdense), act), act)
+    # the generic kernel on the same tile-major int8 matrix (the PagedKVCache-mode path)
+    out2 = torch.zeros((min(M, 8), N), dtype=xd.dtype, device="cuda")
+    assert not gemv(ol, xd, min(M, 8), act, epi=L.EPI_STORE, out=out2, ldo=N)
+    _assert_close(host(out2), round_to(matmul_nt(x[:8], wdense), act), act)
