@@ -1,4 +1,4 @@
-// gemm_skinny.hip -- weight-streaming GEMM for 17..64 activation rows: the decode step of a large batch
+// gemm_skinny.hip -- weight-streaming GEMM for 9..64 activation rows (int8 weights: 1..64): the decode step of a larger batch
 // (BASELINE configs 4 / 5 put 32 / 64 sequences in one batch) and short prefills.
 //
 // Same operator as gemv_mfma.hip (nn.Linear / nn.QuantizedLinear call sites llama.py:64-67,93,143,160-165,
@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemv_phase.h"
@@ -435,12 +436,12 @@ int launch_k(const SkinnyParams& p, int grid, hipStream_t st) {
 template <typename AT, int QB, bool SWIGLU>
 int launch_mt(const SkinnyParams& p, int mt, int grid, hipStream_t st) {
   switch (mt) {
-    case 1: if constexpr (QB == 8) return launch_k<AT, QB, 1, SWIGLU>(p, grid, st); else break;   // int8: every decode step
+    case 1: return launch_k<AT, QB, 1, SWIGLU>(p, grid, st);    // int8: every decode step; 16-bit / int4: 9..16 rows
     case 2: return launch_k<AT, QB, 2, SWIGLU>(p, grid, st);
     case 3: return launch_k<AT, QB, 3, SWIGLU>(p, grid, st);
     case 4: return launch_k<AT, QB, 4, SWIGLU>(p, grid, st);
   }
-  return fail(MI_ERR_INVALID, "gemm_skinny: 17..64 rows (int8: 1..64)");
+  return fail(MI_ERR_INVALID, "gemm_skinny: 1..64 rows");
 }
 
 template <typename AT>
@@ -452,11 +453,20 @@ int launch_at(const SkinnyParams& p, int qb, bool swiglu, int mt, int grid, hipS
 
 }  // namespace
 
+// 16-bit / int4 weights: gemv_mfma.hip serves up to 8 rows, this kernel 9..64 (its 16-row instantiation beats the
+// M <= 16 form of gemv_mfma.hip, which stages all of x per workgroup: Mistral-7B bf16 B = 16 3557 -> 3835 tok/s, int4
+// 4181 -> 5973, Qwen3-14B bf16 1401 -> 2386; at 8 rows and below gemv_mfma.hip wins, 3.59 vs 3.95 ms/step).
+// MI_SKINNY_MIN_ROWS moves the hand-over (A/B).
+static int skinny_min_rows() {
+  static const int v = [] { const char* e = getenv("MI_SKINNY_MIN_ROWS"); return e ? std::max(1, atoi(e)) : 9; }();
+  return v;
+}
+
 bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
   const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 64 == 0;                         // int8 has no M <= 16 kernel of its own: every decode step runs here
-  if (rows < 1 || rows > 64 || (rows <= 16 && !q8)) return false;
+  if (rows < 1 || rows > 64 || (rows <= skinny_min_rows() - 1 && !q8)) return false;
   const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
   const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 128 == 0;

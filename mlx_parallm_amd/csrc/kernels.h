@@ -76,7 +76,7 @@ int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st);
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
                         hipStream_t st, bool block_per_row = false);
 
-// 17..64 rows (decode steps of large batches, short prefills): weight-streaming split-K GEMM (gemm_skinny.hip).
+// 9..64 rows, int8 weights 1..64 (decode steps of larger batches): weight-streaming split-K GEMM (gemm_skinny.hip).
 // c.pro must be PRO_NONE; `ws` >= gemm_skinny_ws_bytes(), `ctr` >= gemm_skinny_groups() words that are zero between
 // launches (the kernel leaves them zero); ksplit = 0 lets the cost model choose.
 bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows);

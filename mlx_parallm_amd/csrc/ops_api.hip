@@ -78,7 +78,7 @@ int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters,
   return finish();
 }
 
-// gemm_skinny.hip on its own: a->M in 17..64, a->pro must be MI_PRO_NONE; ksplit 0 = the cost model's choice
+// gemm_skinny.hip on its own: a->M in 9..64 (int8: 1..64), a->pro must be MI_PRO_NONE; ksplit 0 = the cost model's choice
 // (*ksplit_used returns it); iters >= 1 additionally times `iters` back-to-back launches.
 int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters, float* avg_ms) {
   if (!w || !a) return fail(MI_ERR_INVALID, "null argument");

@@ -125,7 +125,7 @@ def _prompts(cfg, B, L0, seed):
     return toks.astype(np.int32)
 
 
-@pytest.mark.parametrize("B", [17, 40, 64])
+@pytest.mark.parametrize("B", [11, 17, 40, 64])
 @pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
 def test_large_batch_decode_logits_match_oracle(tiny_dirs, name, B):
     d, cfg = tiny_dirs[name]
@@ -198,6 +198,20 @@ def test_large_batch_decode_with_lora(tiny_dirs, tmp_path):
     assert np.abs(want - plain).max() > 0.5                     # the adapter really changes the logits
     assert np.abs(got - want).max() <= 0.08, np.abs(got - want).max()
     model.engine.close()
+
+
+@pytest.mark.parametrize("act,kind", KINDS)
+@pytest.mark.parametrize("M,N,K,ksplit", [(9, 80, 128, 1), (12, 256, 4608, 0), (13, 144, 384, 3), (16, 1040, 1024, 2)])
+def test_16_row_instantiation(act, kind, M, N, K, ksplit):
+    """9..16 rows: the engine hands over from gemv_mfma.hip at 9 rows."""
+    ol, wdense, keep = _weight(kind, N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    xd = dev(x, act)
+    out = torch.full((M + 1, N), 7.0, dtype=xd.dtype, device="cuda")
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE, out=out, ldo=N, ksplit=ksplit)
+    got = host(out)
+    assert np.all(got[M:] == 7.0)
+    _assert_close(got[:M], round_to(matmul_nt(x, wdense), act), act)
 
 
 @pytest.mark.parametrize("act,kind", [("bfloat16", "q8_bf16"), ("float16", "q8_f16")])
