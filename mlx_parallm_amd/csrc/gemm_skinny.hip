@@ -466,7 +466,11 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
   const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 64 == 0;                         // int8 has no M <= 16 kernel of its own: every decode step runs here
-  if (rows < 1 || rows > 64 || (rows <= skinny_min_rows() - 1 && !q8)) return false;
+  // int4: this kernel also wins below 9 rows, on every linear (M = 8, Mistral-7B shapes, us: q|k|v 9.2 vs 12.4, o 9.8 vs
+  // 9.8, gate|up 19.0 vs 24.3, down 14.8 vs 23.7, lm_head 17.7 vs 24.5 -- more than the two RMSNorm launches it adds)
+  static const bool q4_small = getenv("MI_SKINNY_Q4_MIN_ROWS") == nullptr;   // A/B: set = hand-over at skinny_min_rows() as for 16-bit
+  if (rows < 1 || rows > 64) return false;
+  if ((int)rows < skinny_min_rows() && !q8 && !(q4_small && wk_is_quant(W.wk))) return false;
   const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
   const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 128 == 0;

@@ -171,6 +171,7 @@ def test_paired_gemv_launches_are_bit_identical(tiny_dirs, name):
     B = 3
     toks = _left_pad_prompts(cfg, B, 9, ragged=False)
     outs = []
+    model.engine.set_option("skinny_gemm", 0)          # the pairs are built from gemv_mfma.hip's phases (int4 steps default to gemm_skinny.hip)
     for opt in (0, 3):
         model.engine.set_option("fused_gemv_pairs", opt)
         kv = model.engine.new_kv(B, capacity=64, kv_dtype="model")

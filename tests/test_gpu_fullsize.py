@@ -57,7 +57,7 @@ def _greedy(eng, prompts, steps, **opts):
     kv.close()
     for k in opts:
         eng.set_option(k, {"force_generic_gemv": 0, "fused_decode_attention": 1, "prefill_gemm": 1,
-                           "decode_attention_mfma": 1, "fused_gemv_pairs": 0}[k])
+                           "decode_attention_mfma": 1, "fused_gemv_pairs": 0, "skinny_gemm": 1}[k])
     return np.stack(toks), lg
 
 
@@ -132,8 +132,11 @@ def test_alternative_launch_structures_agree(big):
     rng = np.random.default_rng(6)
     p = rng.integers(0, cfg["vocab_size"], size=(8, 300)).astype(np.int32)    # 300 keys: split-KV attention
     base, lb = _greedy(eng, p, 5)
-    paired, lp = _greedy(eng, p, 5, fused_gemv_pairs=3)
-    assert np.array_equal(base, paired) and np.array_equal(lb, lp)            # same kernels, other launch structure: bit-equal
+    # the paired launches are built from gemv_mfma.hip's phases; int4 steps run on gemm_skinny.hip by default
+    single, ls = _greedy(eng, p, 5, skinny_gemm=0)
+    paired, lp = _greedy(eng, p, 5, skinny_gemm=0, fused_gemv_pairs=3)
+    assert np.array_equal(single, paired) and np.array_equal(ls, lp)          # same kernels, other launch structure: bit-equal
+    _same_tokens_up_to_near_ties(base, single, lb, ls)                        # the two streaming kernels
     valu, lv = _greedy(eng, p, 5, decode_attention_mfma=0)
     _same_tokens_up_to_near_ties(base, valu, lb, lv)
     chunked, lc = _greedy(eng, p, 5, prefill_gemm=0)

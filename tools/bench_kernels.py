@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--generic", type=int, default=0)
     ap.add_argument("--tiled", type=int, default=1)
+    ap.add_argument("--skinny", action="store_true", help="time gemm_skinny also for batch <= 16 (set MI_SKINNY_MIN_ROWS=1 for batch <= 8)")
     ap.add_argument("--ksplit", default="0", help="batch > 16 (gemm_skinny): comma-separated K splits to time, 0 = cost model")
     ap.add_argument("--lib", default=None, help="A/B: load this build of libmi355_decode.so instead")
     args = ap.parse_args()
@@ -71,7 +72,7 @@ def main():
         a.pair_offset, a.force_generic = (N // 2 if epi == L.EPI_SWIGLU else 0), args.generic
         torch.cuda.synchronize()
         ms = C.c_float(0)
-        if B > 16:                                    # the split-K streaming GEMM (the engine normalises first)
+        if B > 16 or args.skinny:                     # the split-K streaming GEMM (the engine normalises first)
             a.pro = L.PRO_NONE
             for ks in [int(v) for v in args.ksplit.split(",")]:
                 used = C.c_int(0)
