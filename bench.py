@@ -302,12 +302,15 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(),
+                "frac": round(achieved / 8000.0, 4),
+                "frac_of_achievable": round(achieved / 6290.0, 4),      # of the 6.29 TB/s a streaming kernel reaches (MI355X_MICROARCH.md, HBM)
+                "traffic": pmc_traffic(),
                 "traffic_source": "profiles/round1_pmc_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes; 2xFETCH_SIZE+WRITE_SIZE)",
                 "bytes_per_launch": int(kern_bytes), "avg_launch_ms": round(avg_ms, 5), "launches": n_launch,
             },
             "step_bytes": int(step_bytes),
             "step_hbm_frac": round(step_bytes / (ms_per_step * 1e-3) / 8e12, 4),
+            "step_hbm_frac_of_achievable": round(step_bytes / (ms_per_step * 1e-3) / 6.29e12, 4),
             "prefill_tokens_per_sec": round(world * B * ctx / t_prefill, 1),
             "load_seconds": round(t_load, 2),
         }

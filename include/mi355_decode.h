@@ -181,7 +181,13 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *   "prefill_gemm"            0: prefill through the chunked <= 16-row kernels instead of the tile GEMM (default 1)
  *   "fused_gemv_pairs"        bit 0: o_proj -> gate|up, bit 1: down_proj -> next layer's q|k|v as ONE launch
  *                             each with an in-launch seam (default 0: measured no faster than two launches)
- *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1) */
+ *   "decode_attention_mfma"   0: the VALU form of the fused decode attention also for 16-bit caches (default 1)
+ *   "skinny_gemm"             0: decode steps of 9..64 rows (int4 / int8 weights: of any size) through <= 16-row
+ *                             launches of the M <= 16 kernels instead of the split-K streaming GEMM (default 1)
+ *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1)
+ * Environment switches read once by the library (A/B runs only): MI_SKINNY_MIN_ROWS (hand-over row count for 16-bit
+ * weights, default 9), MI_SKINNY_Q4_MIN_ROWS (set: int4 hands over like 16-bit), MI_GEMM_TILE128 (prefill: always the
+ * 128 x 128 tile), MI_GEMM_B_DIRECT (prefill: W fragments straight from global memory). */
 int mi_engine_set_option(mi_engine* e, const char* key, int64_t value);
 /* Blocks until the engine's stream is idle. */
 int mi_engine_sync(mi_engine* e);
