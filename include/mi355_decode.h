@@ -184,6 +184,8 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *   "decode_attention_mfma"   0: the VALU form of the fused decode attention also for 16-bit caches (default 1)
  *   "skinny_gemm"             0: decode steps of 9..64 rows (int4 / int8 weights: of any size) through <= 16-row
  *                             launches of the M <= 16 kernels instead of the split-K streaming GEMM (default 1)
+ *   "norm_handover"           1: RMSNorm statistics handed from the residual epilogue of one split-K launch to the
+ *                             staging of the next instead of an rmsnorm launch (default 0: measured neutral)
  *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1)
  * Environment switches read once by the library (A/B runs only): MI_SKINNY_MIN_ROWS (hand-over row count for 16-bit
  * weights, default 9), MI_SKINNY_Q4_MIN_ROWS (set: int4 hands over like 16-bit), MI_GEMM_TILE128 (prefill: always the

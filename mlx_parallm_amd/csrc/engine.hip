@@ -104,6 +104,11 @@ struct mi_engine {
   int opt_prefill_gemm = 1;
   int opt_skinny_gemm = 1;      // decode steps of 9..64 rows (int8: 1..64): the split-K weight-streaming GEMM (gemm_skinny.hip)
   int cur_L = 0;                // tokens per sequence of the forward pass being enqueued
+  // RMSNorm hand-over between gemm_skinny launches (GemvCall::sq_out / sq_in): the residual linear in front of a norm
+  // leaves the rows' sums of squares, the normalised linear behind it uses them instead of an rmsnorm launch
+  int opt_norm_handover = 0;    // measured neutral (int4 / int8 +-1 %, Qwen3-14B int4 -3.6 %): off by default
+  float* d_sq = nullptr;        // [4096 tile groups][16 rows]
+  bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0;
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
                                          // Off: measured on Mistral-7B bf16 B=8 the in-launch seam costs what the kernel
                                          // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
@@ -293,22 +298,32 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
 int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_t es_in, size_t es_out,
               const char* prof) {
   c.force_v1 = e->opt_force_v1;
+  const bool sq_was_valid = e->sq_valid;      // whatever runs now consumes or invalidates the hand-over
+  e->sq_valid = false;
   if (e->opt_skinny_gemm && e->cur_L == 1 && gemm_skinny_supported(f.W, c, rows)) {
     // the decode step of a batch of 9..64 sequences (int8 weights: any batch up to 64): W is streamed once, K split over workgroups (gemm_skinny.hip).
     // Decode only: a prefill keeps ONE arithmetic whatever the batch around a sequence (the tile GEMM from 32 rows
     // up, 16-row launches below), which tests/test_gpu_fullsize.py holds bit for bit.
     Prof pr(e, prof);
-    if (c.pro == PRO_NORM) {
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
-      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
-    }
+    const bool handed = sq_was_valid && e->opt_norm_handover && c.pro == PRO_NORM && rows <= 16 && e->sq_src == c.x &&
+                        e->sq_K == f.W.K && c.ldx == f.W.K;
     c.M = (int)rows;
-    if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {
+    if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {     // (normalises on its own when c.pro says so)
       c.lora_t = e->lora_t; c.lora_t_ld = 128;
       MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
     }
+    if (handed) { c.sq_in = e->d_sq; c.sq_parts = e->sq_parts; }
+    else if (c.pro == PRO_NORM) {
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
+      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+    }
     const size_t need = gemm_skinny_ws_bytes(f.W, c, rows);
     const int groups = gemm_skinny_groups(f.W, c, rows);
+    const bool produce = e->opt_norm_handover && c.epi == EPI_RESID && rows <= 16 && groups <= 4096 && c.ldo == f.W.N;
+    if (produce) {
+      if (!e->d_sq) MI_HIP(hipMalloc(&e->d_sq, (size_t)4096 * 16 * sizeof(float)));
+      c.sq_out = e->d_sq;
+    }
     if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
       MI_HIP(hipStreamSynchronize(e->stream));
       if (need > e->sk_ws_cap) {
@@ -324,7 +339,9 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
         e->sk_ctr_cap = cap;
       }
     }
-    return launch_gemm_skinny(f.W, c, rows, e->stream, e->sk_ws, e->sk_ctr);
+    MI_TRY(launch_gemm_skinny(f.W, c, rows, e->stream, e->sk_ws, e->sk_ctr));
+    if (produce) { e->sq_valid = true; e->sq_src = c.resid; e->sq_parts = groups; e->sq_K = f.W.N; }
+    return MI_OK;
   }
   if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {
     // prefill: one MFMA tile GEMM over all rows (the RMSNorm runs as its own row-wise kernel)
@@ -449,6 +466,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
   const int nqkv = (Hq + 2 * Hkv) * D;
   hipStream_t st = e->stream;
   e->cur_L = L;
+  e->sq_valid = false;
 
   auto row_of = [&](int b) { return rows ? rows[b] : b; };
   for (int b = 0; b < B; ++b)
@@ -673,7 +691,7 @@ void mi_engine_destroy(mi_engine* e) {
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
   hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
-  hipFree(e->sk_ws); hipFree(e->sk_ctr);
+  hipFree(e->sk_ws); hipFree(e->sk_ctr); hipFree(e->d_sq);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {
@@ -1053,6 +1071,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "fused_decode_attention") { e->opt_fused_attn = value != 0; return MI_OK; }
   if (k == "prefill_gemm") { e->opt_prefill_gemm = value != 0; return MI_OK; }
   if (k == "skinny_gemm") { e->opt_skinny_gemm = value != 0; return MI_OK; }
+  if (k == "norm_handover") { e->opt_norm_handover = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "tile_weights") {

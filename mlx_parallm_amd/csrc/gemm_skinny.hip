@@ -59,6 +59,10 @@ struct SkinnyParams {
   const void* x; int ldx; int M;
   const void* w; int N, K;
   int epi; void* out; int ldo; void* resid; int pair_offset;
+  // RMSNorm hand-over between two launches of the 16-row instantiation (see "norm hand-over" in the kernel):
+  float* sq_out;                   // producer (residual epilogue): [tile groups][16] sums of h^2 over the group's 128 columns
+  const float* sq_in; int sq_parts;   // consumer: the producer's partial sums and their count
+  const void* norm_w; float eps;   //           x -> w * T(x * rsqrt(mean(x^2) + eps)) while staging
   int ntiles;        // 16-row tiles (tile pairs for SwiGLU)
   int ksplit;        // workgroups per tile group along K
   int nchunks;       // ceil(K / 256)
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
   // slot P * MB + (m ^ ((P & 7) << 1)): writers (8 P x 2 m per 16 lanes) and readers (16 m of one P) both
   // touch 16 different 16-byte columns.
   const AT* xrow[MT];
-  int xk[MT], woff[MT], sxoff[MT];
+  int xk[MT], woff[MT], sxoff[MT], xmi[MT];
   bool xm[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -148,14 +152,24 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
     sxoff[i] = FRAG + ((k8l >> 3) * MB + m) * 4;
     xk[i] = k8l * 8;
     xm[i] = m < p.M;
+    xmi[i] = m;
     xrow[i] = (const AT*)p.x + (size_t)min(m, p.M - 1) * p.ldx;
   }
-  u32x4 xr[MT];
+  // ---- norm hand-over (16-row instantiation).  The linear in front of every RMSNorm is a residual add (o_proj,
+  // down_proj): its epilogue leaves sum(h^2) per row and tile group next to h, and the consumer turns those 32..40
+  // partial sums into rsqrt(mean + eps) and normalises while it stages x -- no launch for the norm, no second pass
+  // over x.  (Letting every workgroup compute the statistics itself from x was measured slower than the launch.)
+  __shared__ float rs_sh[16];
+  const bool norm = (MT == 1) && p.sq_in != nullptr;
+  u32x4 xr[MT], xw[MT];
   auto load_x = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int k = c * SK_KC + xk[i];
       xr[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0));
+      if constexpr (MT == 1) {
+        if (norm) xw[i] = *(const u32x4*)((const AT*)p.norm_w + (k < p.K ? k : 0));
+      }
     }
   };
   auto store_x = [&](int c, unsigned char* buf) {
@@ -163,6 +177,18 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
     for (int i = 0; i < MT; ++i) {
       const bool ok = xm[i] && (c * SK_KC + xk[i] < p.K);
       u32x4 v = ok ? xr[i] : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (MT == 1) {
+        if (norm) {
+          AT* e = (AT*)&v;
+          const AT* we = (const AT*)&xw[i];
+          const float rs = rs_sh[xmi[i]];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const AT xn = (AT)((float)e[j] * rs);               // cast_T(x32 * rsqrt(..))
+            e[j] = (AT)((float)xn * (float)we[j]);               // w * (.)  in T
+          }
+        }
+      }
       if constexpr (QUANT) {
         AT* e = (AT*)&v;
         float sum = 0.f;
@@ -273,6 +299,23 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
   load_x(c0);
 #pragma unroll
   for (int u = 0; u < UK; ++u) issue(u, u_begin + u);
+  if constexpr (MT == 1) {
+    if (norm) {                                   // 16 threads: row statistics from the producer's partial sums
+      if (tid < 16) {
+        float v = 0.f;
+        for (int j = 0; j < p.sq_parts; j += 8) {
+          float pv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pv[u] = p.sq_in[(size_t)min(j + u, p.sq_parts - 1) * 16 + tid];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j + u < p.sq_parts) v += pv[u];
+        }
+        rs_sh[tid] = 1.0f / sqrtf(v / (float)p.K + p.eps);
+      }
+      __syncthreads();
+    }
+  }
   store_x(c0, cur);
   __syncthreads();
 
@@ -345,17 +388,19 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
       }
     }
   }
-  if (!valid) return;
+  const bool want_sq = (MT == 1) && p.sq_out != nullptr;      // (uniform; then spare waves stay for the barriers below)
+  if (!valid && !want_sq) return;
 
   // ================= epilogue: lane (c16, g) holds y[16 mt + 4 g + r][16 tile + c16]
   const int n = tile * 16 + c16;
   AT* out = (AT*)p.out;
+  float hsq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = mt * 16 + g * 4 + r;
-      if (m >= p.M) continue;
+      if (m >= p.M || !valid) continue;
       const float y0 = acc[0][mt][r];
       if constexpr (SWIGLU) {
         const float gt = (float)(AT)y0, up = (float)(AT)acc[NA - 1][mt][r];
@@ -383,10 +428,29 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
         else if (p.epi == EPI_STORE_F32) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
         else {
           AT* h = (AT*)p.resid;
-          h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+          const AT hv = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+          h[(size_t)m * p.ldo + n] = hv;
+          if constexpr (MT == 1) hsq[r] = (float)hv * (float)hv;
         }
       }
     }
+  if constexpr (MT == 1) {
+    if (want_sq) {
+      // sum of h^2 per row over this group's 8 tiles x 16 columns, in a fixed order: [wave][row][column] through LDS,
+      // 256 threads add the 8 waves, a 16-lane butterfly adds the columns
+      float* sq = (float*)smem;                   // (the activation buffers are free: the slice loop ended on a barrier)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq[(wave * 16 + g * 4 + r) * 16 + c16] = hsq[r];
+      __syncthreads();
+      if (tid < 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_NW; ++w) v += sq[(w * 16 + (tid >> 4)) * 16 + (tid & 15)];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if ((tid & 15) == 0) p.sq_out[(size_t)grp * 16 + (tid >> 4)] = v;
+      }
+    }
+  }
 }
 
 int skinny_mt(size_t rows) { return (int)((rows + 15) / 16); }
@@ -485,7 +549,8 @@ int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows) { retur
 
 // c.pro must be PRO_NONE (normalise first); `ws` holds gemm_skinny_ws_bytes(), `ctr` gemm_skinny_groups() zeroed words
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr, int ksplit) {
-  if (c.pro != PRO_NONE) return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first");
+  if (c.pro != PRO_NONE && !(rows <= 16 && c.sq_in != nullptr && c.sq_parts > 0))
+    return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first (or hand over the row sums of squares)");
   SkinnyPlan pl = skinny_plan(W, c, rows);
   if (ksplit > 0) {
     pl.ksplit = std::min(ksplit, pl.nchunks);
@@ -496,6 +561,9 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   p.x = c.x; p.ldx = c.ldx; p.M = (int)rows;
   p.w = W.w; p.N = W.N; p.K = W.K;
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.epi == EPI_SWIGLU ? c.pair_offset : 0;
+  p.sq_out = (pl.mt == 1 && c.epi == EPI_RESID) ? c.sq_out : nullptr;
+  p.sq_in = (pl.mt == 1 && c.pro == PRO_NORM) ? c.sq_in : nullptr; p.sq_parts = c.sq_parts;
+  p.norm_w = c.norm_w; p.eps = c.eps;
   p.ntiles = pl.ntiles; p.ksplit = pl.ksplit; p.nchunks = pl.nchunks;
   p.ws = (float*)ws; p.ctr = ctr;
   p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;

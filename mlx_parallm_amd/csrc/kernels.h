@@ -46,6 +46,11 @@ struct GemvCall {
   const float* lora_t = nullptr;  // [M][2][max_rank] = round(x A) for the (up to 2) adapted row ranges
   int lora_t_ld = 0;
   int force_v1 = 0;
+  // RMSNorm hand-over between two launches of gemm_skinny.hip's 16-row instantiation: a residual epilogue leaves
+  // sum(h^2) per (tile group, row) in sq_out; the next linear (pro = PRO_NORM) reads them as sq_in[sq_parts][16]
+  float* sq_out = nullptr;
+  const float* sq_in = nullptr;
+  int sq_parts = 0;
   void* ev_start = nullptr;       // measurement: hipEvent_t pair stamped with this kernel's own begin / end
   void* ev_stop = nullptr;        // (hipExtLaunchKernelGGL); MFMA path only
 };

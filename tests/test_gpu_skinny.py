@@ -230,3 +230,31 @@ def test_int8_decode_rows(act, kind, M, N, K, ksplit):
     out2 = torch.zeros((min(M, 8), N), dtype=xd.dtype, device="cuda")
     assert not gemv(ol, xd, min(M, 8), act, epi=L.EPI_STORE, out=out2, ldo=N)
     _assert_close(host(out2), round_to(matmul_nt(x[:8], wdense), act), act)
+
+
+@pytest.mark.parametrize("B", [3, 12])
+@pytest.mark.parametrize("name", ["llama_q4_bf16", "llama_q8_f16", "llama_bf16_gqa", "qwen3_bf16"])
+def test_norm_handover_between_launches(tiny_dirs, name, B):
+    """RMSNorm statistics handed from the residual epilogue of one launch to the staging of the next (no rmsnorm
+    launch): logits against the oracle, and against the same steps with the hand-over switched off."""
+    d, cfg = tiny_dirs[name]
+    model = utils.load_model(d, max_positions=256)
+    ref = ref_generate.load(d, max_pos=256)
+    toks = _prompts(cfg, B, 6, seed=100 + B)
+    outs = {}
+    for on in (1, 0):
+        model.engine.set_option("norm_handover", on)
+        kv = model.engine.new_kv(B, capacity=16, kv_dtype="model")
+        cache = ref.make_cache(B, paged=False)
+        model.engine.forward(toks, kv)
+        nxt = np.argmax(ref(toks, cache=cache)[:, -1], axis=-1)[:, None]
+        steps = []
+        for _ in range(3):
+            got = model.engine.forward(nxt.astype(np.int32), kv)
+            want = ref(nxt, cache=cache)[:, -1]
+            assert np.abs(got - want).max() <= 0.08, (on, np.abs(got - want).max())
+            steps.append(got)
+            nxt = np.argmax(want, axis=-1)[:, None]
+        outs[on] = np.stack(steps)
+    assert np.abs(outs[1] - outs[0]).max() <= 0.08
+    model.engine.close()
