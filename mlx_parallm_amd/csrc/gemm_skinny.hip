@@ -534,7 +534,15 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   // 9.8, gate|up 19.0 vs 24.3, down 14.8 vs 23.7, lm_head 17.7 vs 24.5 -- more than the two RMSNorm launches it adds)
   static const bool q4_small = getenv("MI_SKINNY_Q4_MIN_ROWS") == nullptr;   // A/B: set = hand-over at skinny_min_rows() as for 16-bit
   if (rows < 1 || rows > 64) return false;
-  if ((int)rows < skinny_min_rows() && !q8 && !(q4_small && wk_is_quant(W.wk))) return false;
+  // 16-bit weights below the hand-over: only the linears without a norm in front (o_proj, down_proj) whose K leaves
+  // gemv_mfma a short last activation chunk (K mod 4096 in 1..1024: Qwen3-14B's 5120 and 17408) -- M = 8, us: o 14.3 vs
+  // 16.2, down 34.5 vs 45.5, in the bench 1134 -> 1236 tok/s; no RMSNorm launch is added.  (Mistral-7B's down_proj,
+  // K = 14336 = 3.5 chunks, measured neutral: 2213 vs 2203 tok/s, and stays on gemv_mfma.)
+  static const bool ragged_small = getenv("MI_SKINNY_NO_RAGGED_K") == nullptr;
+  const int rem = W.K % 4096;
+  const bool small_ok = q8 || (q4_small && wk_is_quant(W.wk)) ||
+                        (ragged_small && !wk_is_quant(W.wk) && c.pro == PRO_NONE && W.K > 4096 && rem > 0 && rem <= 1024);
+  if ((int)rows < skinny_min_rows() && !small_ok) return false;
   const bool dense = (W.wk == WK_BF16 && c.act == MI_BF16) || (W.wk == WK_F16 && c.act == MI_F16);
   const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 128 == 0;
