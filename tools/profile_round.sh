@@ -15,7 +15,7 @@ PMC_CMD="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
 
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $STATS_CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 python3 "$ROOT/tools/summarize_prof.py" stats "$OUT/stats" "$ROOT/gpurun_out/${TAG}_bench_kernel_stats.csv" \
-  "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 64 --warmup 8   (Mistral-7B bf16, B=8, KV 1024; prefill + 8 warm-up + 64 timed + 64 instrumented decode steps)\nMB=8 kernels are the decode step; gemm_tile / rmsnorm_rows / attn_kernel are the prefill"
+  "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 64 --warmup 8   (Mistral-7B bf16, B=8, KV 1024; prefill + 8 warm-up + 64 timed + 64 instrumented decode steps)\nMB=8 kernels are the decode step; gemm_tile / rmsnorm_rows / attn_kernel are the prefill\nbench.py's own roofline.avg_launch_ms (HIP events around the swiglu kernel) reads 42.7 us in a plain run -- this table's 42.2 us -- and ~46.7 us in the run UNDER rocprofv3 kept next to this file (the profiler lengthens the event bracket, not the kernel)"
 grep '^{' "$OUT/bench_under_rocprof.json" > "$ROOT/gpurun_out/${TAG}_bench_under_rocprof.json"
 
 for CTR in FETCH_SIZE WRITE_SIZE; do
