@@ -94,6 +94,68 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
   }
 }
 
+// The same for 16-bit activations / caches with head_dim 128 (the prefill of both target models): one 256-thread
+// workgroup per token, a lane owns 8 + 8 elements (i .. i+8 and i+64 .. i+72) of one head, 16-byte loads and stores
+// -- the one-wave-per-(token, head) form above is 393 k tiny workgroups of 2-byte accesses at 8 x 1024 tokens
+// (104 us per layer).  Element-wise arithmetic as above; the q/k-norm sum runs over a lane's 16 elements and then over
+// the head's 8 lanes.
+template <typename AT>
+__global__ __launch_bounds__(256) void rope_append_rows_kernel(RopeAppendCall c) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const AttnShape& s = c.s;
+  constexpr int D = 128, D2 = 64;
+  const int row = blockIdx.x, b = row / s.L, t = row % s.L;
+  const int kb = s.rows ? s.rows[b] : b;
+  const int pos = c.offsets[kb] + t;
+  if (pos >= s.cap || pos >= c.max_pos) return;
+  const int nq = s.Hq * D, nh = s.Hq + 2 * s.Hkv;
+  const AT* src_row = (const AT*)c.qkv + (size_t)row * (nq + 2 * s.Hkv * D);
+  for (int task = threadIdx.x; task < nh * 8; task += 256) {     // (nh * 8) % 8 == 0: a head's 8 lanes stay together
+    const int head = task >> 3, i0 = (task & 7) * 8;
+    const AT* src = src_row + (size_t)head * D;
+    u32x4 v1 = *(const u32x4*)(src + i0), v2 = *(const u32x4*)(src + i0 + D2);
+    const bool is_q = head < s.Hq, is_k = !is_q && head < s.Hq + s.Hkv;
+    if (!is_q && !is_k) {                                        // values: plain append
+      AT* dst = (AT*)c.vcache + (((size_t)kb * s.Hkv + (head - s.Hq - s.Hkv)) * s.cap + pos) * D;
+      *(u32x4*)(dst + i0) = v1; *(u32x4*)(dst + i0 + D2) = v2;
+      continue;
+    }
+    AT* e1 = (AT*)&v1;
+    AT* e2 = (AT*)&v2;
+    const AT* nw = (const AT*)(is_q ? c.q_norm_w : c.k_norm_w);
+    if (nw != nullptr) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float a = (float)e1[j], bb = (float)e2[j]; ss = fmaf(a, a, ss); ss = fmaf(bb, bb, ss); }
+      ss = lane8_sum(ss);
+      const float rs = 1.0f / sqrtf(ss / (float)D + c.eps);
+      const u32x4 w1 = *(const u32x4*)(nw + i0), w2 = *(const u32x4*)(nw + i0 + D2);
+      const AT* q1 = (const AT*)&w1;
+      const AT* q2 = (const AT*)&w2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e1[j] = (AT)((float)(AT)((float)e1[j] * rs) * (float)q1[j]);
+        e2[j] = (AT)((float)(AT)((float)e2[j] * rs) * (float)q2[j]);
+      }
+    }
+    const f32x4* ct = (const f32x4*)(c.cos_tab + (size_t)pos * D2 + i0);
+    const f32x4* st = (const f32x4*)(c.sin_tab + (size_t)pos * D2 + i0);
+    const f32x4 c0 = ct[0], c1 = ct[1], s0 = st[0], s1 = st[1];
+    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x1 = (float)e1[j], x2 = (float)e2[j];
+      e1[j] = (AT)(x1 * cs[j] - x2 * sn[j]);
+      e2[j] = (AT)(x1 * sn[j] + x2 * cs[j]);
+    }
+    AT* dst = is_q ? (AT*)c.q_out + (size_t)row * nq + (size_t)head * D
+                   : (AT*)c.kcache + (((size_t)kb * s.Hkv + (head - s.Hq)) * s.cap + pos) * D;
+    *(u32x4*)(dst + i0) = v1; *(u32x4*)(dst + i0 + D2) = v2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // attention: grid (nsplit, B*Hkv, L), block 256 (4 waves).  Wave w, lane group gq = lane>>4
 // handles key positions s0 + 16*i + 4*w + gq; the 16 lanes of a group each own D/16 elements.
@@ -273,6 +335,13 @@ int launch_attn_d(const AttnCall& c, hipStream_t st) {
 int launch_rope_append(const RopeAppendCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   if (s.D % 2 != 0) return fail(MI_ERR_UNSUPPORTED, "rope: head_dim must be even");
+  if (s.D == 128 && s.rnd == RND_NONE && s.L > 1 && s.kv == s.act && (s.act == MI_BF16 || s.act == MI_F16)) {
+    const dim3 grid_r(s.B * s.L), block_r(256);
+    if (s.act == MI_BF16) hipLaunchKernelGGL(rope_append_rows_kernel<bf16>, grid_r, block_r, 0, st, c);
+    else hipLaunchKernelGGL(rope_append_rows_kernel<f16>, grid_r, block_r, 0, st, c);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   const dim3 grid(s.Hq + 2 * s.Hkv, s.B * s.L), block(64);
 #define RA(AT, KT) hipLaunchKernelGGL((rope_append_kernel<AT, KT>), grid, block, 0, st, c)
   if (s.act == MI_F32 && s.kv == MI_F32) RA(float, float);

@@ -346,8 +346,8 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {
     // prefill: one MFMA tile GEMM over all rows (the RMSNorm runs as its own row-wise kernel)
     Prof pr(e, prof);
-    if (c.pro == PRO_NORM) {
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream));
+    if (c.pro == PRO_NORM) {    // (one workgroup per row also here: one L2 round trip per row instead of a wave's 16)
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
     void* scratch = nullptr;
