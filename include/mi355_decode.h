@@ -182,7 +182,7 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *   "fused_gemv_pairs"        bit 0: o_proj -> gate|up, bit 1: down_proj -> next layer's q|k|v as ONE launch
  *                             each with an in-launch seam (default 0: measured no faster than two launches)
  *   "decode_attention_mfma"   0: the VALU form of the fused decode attention also for 16-bit caches (default 1)
- *   "skinny_gemm"             0: decode steps of 9..64 rows (int4 / int8 weights: of any size) through <= 16-row
+ *   "skinny_gemm"             0: decode steps of 9..128 rows (int4 / int8 weights: of any size) through <= 16-row
  *                             launches of the M <= 16 kernels instead of the split-K streaming GEMM (default 1)
  *   "norm_handover"           1: RMSNorm statistics handed from the residual epilogue of one split-K launch to the
  *                             staging of the next instead of an rmsnorm launch (default 0: measured neutral)

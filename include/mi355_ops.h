@@ -83,7 +83,7 @@ int mi_op_gemv(const mi_op_linear* w, const mi_op_gemv_args* a);
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a);
 /* launches the same call `iters` times back to back and returns the mean launch time (HIP events) */
 int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
-/* the split-K weight-streaming GEMM the engine uses for decode steps of 9..64 rows (int8 weights: 1..64), on its own:
+/* the split-K weight-streaming GEMM the engine uses for decode steps of 9..128 rows (int4 / int8 weights: 1..128), on its own:
  * a->M in that range, a->pro = MI_PRO_NONE, tile-major 16-bit, int4 or int8 (group 64) weights.  ksplit 0 = the library's
  * cost model (returned in *ksplit_used); iters >= 1 also times that many back-to-back launches into *avg_ms. */
 int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters,

@@ -102,7 +102,7 @@ struct mi_engine {
   int opt_attn_mfma = 1;                 // decode attention on the matrix cores where the shape allows
   int opt_tile_weights = 1;
   int opt_prefill_gemm = 1;
-  int opt_skinny_gemm = 1;      // decode steps of 9..64 rows (int8: 1..64): the split-K weight-streaming GEMM (gemm_skinny.hip)
+  int opt_skinny_gemm = 1;      // decode steps of 9..128 rows (int4 / int8: 1..128): the split-K weight-streaming GEMM (gemm_skinny.hip)
   int cur_L = 0;                // tokens per sequence of the forward pass being enqueued
   // RMSNorm hand-over between gemm_skinny launches (GemvCall::sq_out / sq_in): the residual linear in front of a norm
   // leaves the rows' sums of squares, the normalised linear behind it uses them instead of an rmsnorm launch
@@ -301,7 +301,7 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   const bool sq_was_valid = e->sq_valid;      // whatever runs now consumes or invalidates the hand-over
   e->sq_valid = false;
   if (e->opt_skinny_gemm && e->cur_L == 1 && gemm_skinny_supported(f.W, c, rows)) {
-    // the decode step of a batch of 9..64 sequences (int8 weights: any batch up to 64): W is streamed once, K split over workgroups (gemm_skinny.hip).
+    // the decode step of a batch of 9..128 sequences (int4 / int8 weights: any batch up to 128): W is streamed once, K split over workgroups (gemm_skinny.hip).
     // Decode only: a prefill keeps ONE arithmetic whatever the batch around a sequence (the tile GEMM from 32 rows
     // up, 16-row launches below), which tests/test_gpu_fullsize.py holds bit for bit.
     Prof pr(e, prof);

@@ -1,4 +1,4 @@
-// gemm_skinny.hip -- weight-streaming GEMM for 9..64 activation rows (int8 weights: 1..64): the decode step of a larger batch
+// gemm_skinny.hip -- weight-streaming GEMM for 9..128 activation rows (int4 / int8 weights: 1..128): the decode step of a larger batch
 // (BASELINE configs 4 / 5 put 32 / 64 sequences in one batch) and short prefills.
 //
 // Same operator as gemv_mfma.hip (nn.Linear / nn.QuantizedLinear call sites llama.py:64-67,93,143,160-165,
@@ -76,7 +76,7 @@ struct SkinnyParams {
 
 // QB: 0 = dense 16-bit weights, 4 / 8 = MLX-affine int4 / int8 codes (group 64)
 template <typename AT, int QB, int MT, bool SWIGLU>
-__global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
+__global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT >= 5) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
   constexpr bool Q4 = QB == 4, Q8 = QB == 8, QUANT = QB != 0;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
   constexpr int UK = (Q4 ? 4 : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
@@ -453,7 +453,11 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3)) ? 2 :
   }
 }
 
-int skinny_mt(size_t rows) { return (int)((rows + 15) / 16); }
+// 16-row tiles of activations per workgroup: 1, 2, 3, 4, 6 or 8 (65..96 rows -> 6, 97..128 -> 8)
+int skinny_mt(size_t rows) {
+  const int mt = (int)((rows + 15) / 16);
+  return mt == 5 ? 6 : mt == 7 ? 8 : mt;
+}
 
 struct SkinnyPlan { int ntiles, ngroups, nchunks, ksplit, mt, na; size_t ws_bytes; };
 
@@ -489,7 +493,7 @@ int launch_k(const SkinnyParams& p, int grid, hipStream_t st) {
   const size_t lds = 2 * ((size_t)16 * MT * 512 + (QB ? 16 * MT * 16 : 0));
   static bool attr_done = false;
   if (!attr_done) {
-    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 512 + 64 * 16)));
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 512 + 128 * 16)));
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(SK_NW * 64), lds, st, p);
@@ -504,8 +508,10 @@ int launch_mt(const SkinnyParams& p, int mt, int grid, hipStream_t st) {
     case 2: return launch_k<AT, QB, 2, SWIGLU>(p, grid, st);
     case 3: return launch_k<AT, QB, 3, SWIGLU>(p, grid, st);
     case 4: return launch_k<AT, QB, 4, SWIGLU>(p, grid, st);
+    case 6: return launch_k<AT, QB, 6, SWIGLU>(p, grid, st);
+    case 8: return launch_k<AT, QB, 8, SWIGLU>(p, grid, st);
   }
-  return fail(MI_ERR_INVALID, "gemm_skinny: 1..64 rows");
+  return fail(MI_ERR_INVALID, "gemm_skinny: 1..128 rows");
 }
 
 template <typename AT>
@@ -533,7 +539,8 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   // int4: this kernel also wins below 9 rows, on every linear (M = 8, Mistral-7B shapes, us: q|k|v 9.2 vs 12.4, o 9.8 vs
   // 9.8, gate|up 19.0 vs 24.3, down 14.8 vs 23.7, lm_head 17.7 vs 24.5 -- more than the two RMSNorm launches it adds)
   static const bool q4_small = getenv("MI_SKINNY_Q4_MIN_ROWS") == nullptr;   // A/B: set = hand-over at skinny_min_rows() as for 16-bit
-  if (rows < 1 || rows > 64) return false;
+  if (rows < 1 || rows > 128) return false;
+  if (wk_is_quant(W.wk) && !q8 && rows > 96) return false;     // (the 128-row int4 SwiGLU instantiation would spill registers)
   // 16-bit weights below the hand-over: only the linears without a norm in front (o_proj, down_proj) whose K leaves
   // gemv_mfma a short last activation chunk (K mod 4096 in 1..1024: Qwen3-14B's 5120 and 17408) -- M = 8, us: o 14.3 vs
   // 16.2, down 34.5 vs 45.5, in the bench 1134 -> 1236 tok/s; no RMSNorm launch is added.  (Mistral-7B's down_proj,

@@ -78,7 +78,7 @@ int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters,
   return finish();
 }
 
-// gemm_skinny.hip on its own: a->M in 9..64 (int8: 1..64), a->pro must be MI_PRO_NONE; ksplit 0 = the cost model's choice
+// gemm_skinny.hip on its own: a->M in 9..128 (int4 / int8: 1..128), a->pro must be MI_PRO_NONE; ksplit 0 = the cost model's choice
 // (*ksplit_used returns it); iters >= 1 additionally times `iters` back-to-back launches.
 int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters, float* avg_ms) {
   if (!w || !a) return fail(MI_ERR_INVALID, "null argument");
@@ -88,7 +88,7 @@ int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int kspli
   if (!gemm_skinny_supported(W, c, (size_t)c.M)) return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_skinny: call not supported by this kernel");
   const int groups = gemm_skinny_groups(W, c, (size_t)c.M);
   void* ws = nullptr; unsigned* ctr = nullptr;
-  MI_HIP(hipMalloc(&ws, (size_t)W.N * 4096 + 1024));                  // 16 slices x N x 64 rows x 4 B: any ksplit
+  MI_HIP(hipMalloc(&ws, (size_t)W.N * 8192 + 1024));                  // 16 slices x N x 128 rows x 4 B: any ksplit
   MI_HIP(hipMalloc(&ctr, (size_t)groups * sizeof(unsigned)));
   MI_HIP(hipMemset(ctr, 0, (size_t)groups * sizeof(unsigned)));
   if (ksplit_used) *ksplit_used = ksplit > 0 ? ksplit : gemm_skinny_ksplit(W, c, (size_t)c.M);

@@ -46,8 +46,12 @@ KINDS = [("bfloat16", "bf16"), ("float16", "f16"), ("bfloat16", "q4_bf16"), ("fl
     (40, 144, 4608, 5),      # 18 chunks in unequal slices, 48-row fragments
     (64, 1040, 1024, 0),     # cost model's split, 65 tiles
     (33, 128, 384, 3),       # last chunk half full (K % 256 = 128)
+    (80, 272, 1024, 2),      # 96-row fragments (6 tiles)
+    (128, 144, 768, 0),      # 128-row fragments (8 tiles; int4 stops at 96 rows)
 ])
 def test_store_matches_oracle_and_is_deterministic(act, kind, M, N, K, ksplit):
+    if M > 96 and kind.startswith("q4"):
+        pytest.skip("int4: up to 96 rows")
     ol, wdense, keep = _weight(kind, N, K)
     x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
     xd = dev(x, act)
@@ -125,7 +129,7 @@ def _prompts(cfg, B, L0, seed):
     return toks.astype(np.int32)
 
 
-@pytest.mark.parametrize("B", [11, 17, 40, 64])
+@pytest.mark.parametrize("B", [11, 17, 40, 64, 100])
 @pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
 def test_large_batch_decode_logits_match_oracle(tiny_dirs, name, B):
     d, cfg = tiny_dirs[name]
@@ -258,3 +262,21 @@ def test_norm_handover_between_launches(tiny_dirs, name, B):
         outs[on] = np.stack(steps)
     assert np.abs(outs[1] - outs[0]).max() <= 0.08
     model.engine.close()
+
+
+@pytest.mark.parametrize("act,kind", KINDS)
+@pytest.mark.parametrize("M", [72, 120])
+def test_swiglu_above_64_rows(act, kind, M):
+    if M > 96 and kind.startswith("q4"):
+        pytest.skip("int4: up to 96 rows")
+    I, K = 176, 768
+    ol, wdense, keep = _weight(kind, 2 * I, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    g = round_to(matmul_nt(x, wdense[:I]), act)
+    u = round_to(matmul_nt(x, wdense[I:]), act)
+    sig = round_to(1.0 / (1.0 + np.exp(-g.astype(np.float64))), act)
+    want = round_to(round_to(g * sig, act) * u, act)
+    xd = dev(x, act)
+    out = torch.zeros((M, I), dtype=xd.dtype, device="cuda")
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, ksplit=2)
+    _assert_close(host(out), want, act)
