@@ -314,7 +314,7 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     }
     if (handed) { c.sq_in = e->d_sq; c.sq_parts = e->sq_parts; }
     else if (c.pro == PRO_NORM) {
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
     const size_t need = gemm_skinny_ws_bytes(f.W, c, rows);
@@ -367,6 +367,44 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       c.M = (int)rows;
       MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
       MI_TRY(launch_lora_up_add(f.W, c, e->lora_t, 128, e->stream));
+    }
+    return MI_OK;
+  }
+  if (e->opt_skinny_gemm && c.act == MI_F32 && rows > 16 && gemm_skinny_supported(f.W, c, 16)) {
+    // PagedKVCache mode, more than 16 rows (its prefill): 16 rows per launch of the float32-activation streaming kernel
+    // (each row's arithmetic is that of a decode step, whatever the batch); the generic kernel took 8 rows per pass
+    // over W.  A tile GEMM with the three-way split of x is the next step for this mode.
+    Prof pr(e, prof);
+    if (c.pro == PRO_NORM) {
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
+      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+    }
+    GemvCall c16 = c; c16.M = 16;
+    const size_t need = gemm_skinny_ws_bytes(f.W, c16, 16);
+    const int groups = gemm_skinny_groups(f.W, c16, 16);
+    if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
+      MI_HIP(hipStreamSynchronize(e->stream));
+      if (need > e->sk_ws_cap) {
+        hipFree(e->sk_ws); e->sk_ws = nullptr; e->sk_ws_cap = 0;
+        MI_HIP(hipMalloc(&e->sk_ws, need));
+        e->sk_ws_cap = need;
+      }
+      if (groups > e->sk_ctr_cap) {
+        hipFree(e->sk_ctr); e->sk_ctr = nullptr; e->sk_ctr_cap = 0;
+        const int cap = std::max(groups, 4096);
+        MI_HIP(hipMalloc(&e->sk_ctr, (size_t)cap * sizeof(unsigned)));
+        MI_HIP(hipMemsetAsync(e->sk_ctr, 0, (size_t)cap * sizeof(unsigned), e->stream));
+        e->sk_ctr_cap = cap;
+      }
+    }
+    const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
+    for (size_t r = 0; r < rows; r += 16) {
+      GemvCall cc = c;
+      cc.M = (int)std::min<size_t>(16, rows - r);
+      cc.x = x0 + r * (size_t)c.ldx * es_in;
+      if (o0) cc.out = o0 + r * (size_t)c.ldo * es_out;
+      if (r0) cc.resid = r0 + r * (size_t)c.ldo * es_in;
+      MI_TRY(launch_gemm_skinny(f.W, cc, (size_t)cc.M, e->stream, e->sk_ws, e->sk_ctr));
     }
     return MI_OK;
   }

@@ -457,6 +457,32 @@ __global__ __launch_bounds__(256) void rmsnorm_row_block_kernel(const AT* x, int
   }
 }
 
+// float32 storage with the run-time logical rounding (PagedKVCache mode): out = rnd(w * rnd(x * rsqrt(mean(x^2) + eps)))
+__global__ __launch_bounds__(256) void rmsnorm_row_block_f32_kernel(const float* x, int ldx, const float* w, float* out, int ldo,
+                                                                    int H, float eps, int rnd) {
+  __shared__ float part[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  for (int k = tid * 4; k < H; k += 1024) {
+    const f32x4 v = *(const f32x4*)(xr + k);
+    ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  const float rs = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)H + eps);
+  for (int k = tid * 4; k < H; k += 1024) {
+    const f32x4 v = *(const f32x4*)(xr + k), wv = *(const f32x4*)(w + k);
+    f32x4 o;
+    o.x = round_rt(round_rt(v.x * rs, rnd) * wv.x, rnd);
+    o.y = round_rt(round_rt(v.y * rs, rnd) * wv.y, rnd);
+    o.z = round_rt(round_rt(v.z * rs, rnd) * wv.z, rnd);
+    o.w = round_rt(round_rt(v.w * rs, rnd) * wv.w, rnd);
+    *(f32x4*)(out + (size_t)row * ldo + k) = o;
+  }
+}
+
 template <typename AT>
 int launch_rmsnorm_block(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, hipStream_t st) {
   const int np = (H / 8 + 255) / 256;
@@ -493,8 +519,14 @@ bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
 }
 
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
-                        hipStream_t st, bool block_per_row) {
+                        hipStream_t st, bool block_per_row, int rnd) {
   if (H % 8 != 0) return fail(MI_ERR_UNSUPPORTED, "rmsnorm_rows: hidden size must be a multiple of 8");
+  if (act == MI_F32) {
+    hipLaunchKernelGGL(rmsnorm_row_block_f32_kernel, dim3(rows), dim3(256), 0, st, (const float*)x, ldx, (const float*)w,
+                       (float*)out, ldo, H, eps, rnd);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   if (block_per_row && H <= 8192) {
     if (act == MI_BF16) return launch_rmsnorm_block<bf16>(x, ldx, w, out, ldo, rows, H, eps, st);
     if (act == MI_F16) return launch_rmsnorm_block<f16>(x, ldx, w, out, ldo, rows, H, eps, st);

@@ -63,6 +63,7 @@ struct SkinnyParams {
   float* sq_out;                   // producer (residual epilogue): [tile groups][16] sums of h^2 over the group's 128 columns
   const float* sq_in; int sq_parts;   // consumer: the producer's partial sums and their count
   const void* norm_w; float eps;   //           x -> w * T(x * rsqrt(mean(x^2) + eps)) while staging
+  int rnd;                         // float32 activations: logical rounding of the outputs (RND_*)
   int ntiles;        // 16-row tiles (tile pairs for SwiGLU)
   int ksplit;        // workgroups per tile group along K
   int nchunks;       // ceil(K / 256)
@@ -75,16 +76,23 @@ struct SkinnyParams {
 };
 
 // QB: 0 = dense 16-bit weights, 4 / 8 = MLX-affine int4 / int8 codes (group 64)
-template <typename AT, int QB, int MT, bool SWIGLU>
+// X32: float32 activations (the PagedKVCache mode of a 16-bit model): x is split exactly into three 16-bit
+// terms, x = hi + mid + lo, staged as three fragment images and multiplied by three MFMAs per weight fragment -- every
+// product is exact in the float32 accumulator, so the result is a float32 dot product in another summation order.
+// Outputs stay float32 with the run-time logical rounding `rnd` (layer 0 of that mode still rounds like the model).
+template <typename AT, int QB, int MT, bool SWIGLU, bool X32 = false>
 __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT >= 5) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
   constexpr bool Q4 = QB == 4, Q8 = QB == 8, QUANT = QB != 0;
+  static_assert(!X32 || (QB == 0 && MT == 1), "float32 activations: dense weights, 16-row instantiation");
+  using XT = typename std::conditional<X32, float, AT>::type;
+  constexpr int NIMG = X32 ? 3 : 1;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
   constexpr int UK = (Q4 ? 4 : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
   constexpr int UPC = Q4 ? 2 : Q8 ? 4 : 8;  // loads per chunk (a load covers 128 / 64 / 32 k)
   constexpr int CPI = UK > UPC ? UK / UPC : 1;   // chunks per trip of the loop body (the slot ring has UK entries)
   constexpr int UB = Q4 ? 1152 : Q8 ? 1088 : 1024;   // bytes of one tile-major block
   constexpr int FRAG = MB * 512;            // fragment bytes per buffer (MB x 256 x 2)
-  constexpr int BUF = FRAG + (QUANT ? MB * 16 : 0);   // + sum(x) per (64-group, row) for the quantisation bias term
+  constexpr int BUF = NIMG * FRAG + (QUANT ? MB * 16 : 0);   // + sum(x) per (64-group, row) for the quantisation bias term
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int last_sh;
 
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // of a row.  Piece P of the chunk (dense: k/8; int4: the nibble-order permutation of gemv_phase.h) lands at
   // slot P * MB + (m ^ ((P & 7) << 1)): writers (8 P x 2 m per 16 lanes) and readers (16 m of one P) both
   // touch 16 different 16-byte columns.
-  const AT* xrow[MT];
+  const XT* xrow[MT];
   int xk[MT], woff[MT], sxoff[MT], xmi[MT];
   bool xm[MT];
 #pragma unroll
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
     xk[i] = k8l * 8;
     xm[i] = m < p.M;
     xmi[i] = m;
-    xrow[i] = (const AT*)p.x + (size_t)min(m, p.M - 1) * p.ldx;
+    xrow[i] = (const XT*)p.x + (size_t)min(m, p.M - 1) * p.ldx;
   }
   // ---- norm hand-over (16-row instantiation).  The linear in front of every RMSNorm is a residual add (o_proj,
   // down_proj): its epilogue leaves sum(h^2) per row and tile group next to h, and the consumer turns those 32..40
@@ -161,12 +169,13 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // over x.  (Letting every workgroup compute the statistics itself from x was measured slower than the launch.)
   __shared__ float rs_sh[16];
   const bool norm = (MT == 1) && p.sq_in != nullptr;
-  u32x4 xr[MT], xw[MT];
+  u32x4 xr[MT], xw[MT], xr2[X32 ? MT : 1];
   auto load_x = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int k = c * SK_KC + xk[i];
       xr[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0));
+      if constexpr (X32) xr2[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0) + 4);
       if constexpr (MT == 1) {
         if (norm) xw[i] = *(const u32x4*)((const AT*)p.norm_w + (k < p.K ? k : 0));
       }
@@ -176,6 +185,24 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const bool ok = xm[i] && (c * SK_KC + xk[i] < p.K);
+      if constexpr (X32) {
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        const u32x4 f0 = ok ? xr[i] : z4, f1 = ok ? xr2[i] : z4;
+        const float xf[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                             __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
+        AT hi[8], mid[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          hi[j] = (AT)xf[j];
+          const float r1 = xf[j] - (float)hi[j];
+          mid[j] = (AT)r1;
+          lo[j] = (AT)(r1 - (float)mid[j]);
+        }
+        *(u32x4*)(buf + woff[i]) = *(const u32x4*)hi;
+        *(u32x4*)(buf + FRAG + woff[i]) = *(const u32x4*)mid;
+        *(u32x4*)(buf + 2 * FRAG + woff[i]) = *(const u32x4*)lo;
+        continue;
+      }
       u32x4 v = ok ? xr[i] : u32x4{0u, 0u, 0u, 0u};
       if constexpr (MT == 1) {
         if (norm) {
@@ -244,13 +271,17 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         }
       }
     } else if constexpr (!Q4) {
-      u32x4 af[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const u32x4*)(cur + lane_off[i & 1] + (i * 4 * MB + mt * 16) * 16);
+      for (int img = 0; img < NIMG; ++img) {
+        u32x4 af[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
+          af[mt] = *(const u32x4*)(cur + img * FRAG + lane_off[i & 1] + (i * 4 * MB + mt * 16) * 16);
 #pragma unroll
-        for (int a = 0; a < NA; ++a) acc[a][mt] = mfma16<AT>(af[mt], wr[a][slot], acc[a][mt]);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int a = 0; a < NA; ++a) acc[a][mt] = mfma16<AT>(af[mt], wr[a][slot], acc[a][mt]);
+      }
     } else {
       // (see Phase::mfma_u) after the swap {x,y} = quant group A, {z,w} = group B in every lane
       uint32_t dw[NA][4];
@@ -402,6 +433,24 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       const int m = mt * 16 + g * 4 + r;
       if (m >= p.M || !valid) continue;
       const float y0 = acc[0][mt][r];
+      if constexpr (X32) {                        // float32 storage, run-time logical rounding (gemv_v1.hip's epilogue)
+        float* o32 = (float*)p.out;
+        if constexpr (SWIGLU) {
+          const float gt = round_rt(y0, p.rnd), up = round_rt(acc[NA - 1][mt][r], p.rnd);
+          const float sig = round_rt(1.0f / (1.0f + expf(-gt)), p.rnd);
+          const float sl = round_rt(gt * sig, p.rnd);
+          o32[(size_t)m * p.ldo + n] = round_rt(sl * up, p.rnd);
+        } else {
+          const float y = round_rt(y0, p.rnd);
+          if (p.epi == EPI_RESID) {
+            float* h = (float*)p.resid;
+            h[(size_t)m * p.ldo + n] = round_rt(h[(size_t)m * p.ldo + n] + y, p.rnd);
+          } else {
+            o32[(size_t)m * p.ldo + n] = y;     // EPI_STORE and EPI_STORE_F32 coincide
+          }
+        }
+        continue;
+      }
       if constexpr (SWIGLU) {
         const float gt = (float)(AT)y0, up = (float)(AT)acc[NA - 1][mt][r];
         const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
@@ -533,7 +582,15 @@ static int skinny_min_rows() {
 }
 
 bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
-  if (c.force_v1 || c.rnd != RND_NONE || W.layout != 1) return false;
+  if (c.force_v1 || W.layout != 1) return false;
+  // float32 activations on 16-bit dense weights (PagedKVCache mode): the 16-row instantiation with x split three ways
+  if (c.act == MI_F32) {
+    static const bool x32_ok = getenv("MI_SKINNY_NO_F32") == nullptr;
+    const int n32 = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
+    return x32_ok && W.wk == WK_BF16 && rows >= 1 && rows <= 16 && W.K % 32 == 0 && c.ldx % 4 == 0 && n32 % 16 == 0 &&
+           W.lora_b[0] == nullptr && W.lora_b[1] == nullptr;
+  }
+  if (c.rnd != RND_NONE) return false;
   const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 64 == 0;                         // int8 has no M <= 16 kernel of its own: every decode step runs here
   // int4: this kernel also wins below 9 rows, on every linear (M = 8, Mistral-7B shapes, us: q|k|v 9.2 vs 12.4, o 9.8 vs
@@ -578,7 +635,7 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.epi == EPI_SWIGLU ? c.pair_offset : 0;
   p.sq_out = (pl.mt == 1 && c.epi == EPI_RESID) ? c.sq_out : nullptr;
   p.sq_in = (pl.mt == 1 && c.pro == PRO_NORM) ? c.sq_in : nullptr; p.sq_parts = c.sq_parts;
-  p.norm_w = c.norm_w; p.eps = c.eps;
+  p.norm_w = c.norm_w; p.eps = c.eps; p.rnd = c.rnd;
   p.ntiles = pl.ntiles; p.ksplit = pl.ksplit; p.nchunks = pl.nchunks;
   p.ws = (float*)ws; p.ctr = ctr;
   p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;
@@ -588,6 +645,16 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   const int qb = (W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16) ? 8 : wk_is_quant(W.wk) ? 4 : 0;
   const bool sw = c.epi == EPI_SWIGLU;
   const int grid = pl.ngroups * pl.ksplit;
+  if (c.act == MI_F32) {
+    p.sq_out = nullptr; p.sq_in = nullptr;
+    auto launch32 = [&](auto kern) -> int {
+      const size_t lds = 2 * (size_t)3 * 16 * 512;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(SK_NW * 64), lds, st, p);
+      MI_HIP(hipGetLastError());
+      return MI_OK;
+    };
+    return sw ? launch32(skinny_kernel<bf16, 0, 1, true, true>) : launch32(skinny_kernel<bf16, 0, 1, false, true>);
+  }
   return c.act == MI_BF16 ? launch_at<bf16>(p, qb, sw, pl.mt, grid, st) : launch_at<f16>(p, qb, sw, pl.mt, grid, st);
 }
 

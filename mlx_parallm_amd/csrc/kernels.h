@@ -78,8 +78,9 @@ size_t dequant_hilo_bytes(int N, int K);
 int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st);
 // block_per_row: one workgroup per row, row in registers -- for the few rows of a decode step (default: one wave
 // per row, the prefill's kernel; the two add the squares in different orders)
+// act = MI_F32: float32 rows and weights with the run-time logical rounding `rnd` (PagedKVCache mode)
 int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, int act,
-                        hipStream_t st, bool block_per_row = false);
+                        hipStream_t st, bool block_per_row = false, int rnd = 0);
 
 // 9..64 rows, int8 weights 1..64 (decode steps of larger batches): weight-streaming split-K GEMM (gemm_skinny.hip).
 // c.pro must be PRO_NONE; `ws` >= gemm_skinny_ws_bytes(), `ctr` >= gemm_skinny_groups() words that are zero between

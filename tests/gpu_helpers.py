@@ -88,11 +88,12 @@ def close_frac(got: np.ndarray, want: np.ndarray, dtype: str, atol: float = 0.0)
     return float(np.mean(np.abs(got - want) > tol))
 
 
-def gemm_skinny(ol: L.OpLinear, x, M, act, *, epi=0, out=None, ldo=0, resid=None, pair_offset=0, ksplit=0, iters=0, ldx=None):
+def gemm_skinny(ol: L.OpLinear, x, M, act, *, epi=0, out=None, ldo=0, resid=None, pair_offset=0, ksplit=0, iters=0, ldx=None,
+                rnd=0):
     """gemm_skinny.hip on its own (17..64 rows) -> (ksplit used, mean launch ms or None)."""
     a = L.OpGemvArgs()
     a.x = x.data_ptr(); a.ldx = ldx if ldx is not None else x.shape[-1]; a.M = M
-    a.act = MIDT[act]; a.rnd = 0; a.pro = 0; a.epi = epi; a.norm_w = 0; a.eps = 0.0; a.ldo = ldo
+    a.act = MIDT[act]; a.rnd = rnd; a.pro = 0; a.epi = epi; a.norm_w = 0; a.eps = 0.0; a.ldo = ldo
     a.out = out.data_ptr() if out is not None else 0
     a.resid = resid.data_ptr() if resid is not None else 0
     a.pair_offset = pair_offset; a.force_generic = 0

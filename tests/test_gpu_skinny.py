@@ -280,3 +280,35 @@ def test_swiglu_above_64_rows(act, kind, M):
     out = torch.zeros((M, I), dtype=xd.dtype, device="cuda")
     gemm_skinny(ol, xd, M, act, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, ksplit=2)
     _assert_close(host(out), want, act)
+
+
+@pytest.mark.parametrize("M,N,K,ksplit", [(1, 80, 128, 1), (8, 256, 4608, 0), (16, 144, 384, 3)])
+@pytest.mark.parametrize("rnd", [L.RND_NONE, L.RND_BF16])
+def test_float32_activations_on_bf16_weights(M, N, K, ksplit, rnd):
+    """PagedKVCache mode: float32 activations, 16-bit weights.  x = hi + mid + lo exactly, three MFMAs per
+    weight fragment: a float32 dot product in another summation order; outputs float32 with the logical rounding."""
+    ol, wdense, keep = _weight("bf16", N, K)
+    x = RNG.standard_normal((M, K)).astype(np.float32)
+    if rnd:
+        x = round_to(x, "bfloat16")
+    xd = dev(x, "float32")
+    want = matmul_nt(x, wdense)
+    if rnd:
+        want = round_to(want, "bfloat16")
+    out = torch.full((M + 1, N), 7.0, dtype=torch.float32, device="cuda")
+    gemm_skinny(ol, xd, M, "float32", epi=L.EPI_STORE, out=out, ldo=N, ksplit=ksplit, rnd=rnd)
+    got = host(out)
+    assert np.all(got[M:] == 7.0)
+    _assert_close(got[:M], want, "bfloat16" if rnd else "float32")
+    # residual and SwiGLU epilogues in float32
+    h = RNG.standard_normal((M, N)).astype(np.float32)
+    hd = dev(h, "float32")
+    gemm_skinny(ol, xd, M, "float32", epi=L.EPI_RESID, resid=hd, ldo=N, ksplit=ksplit, rnd=0)
+    _assert_close(host(hd), h + matmul_nt(x, wdense), "float32", scale=4.0)
+    if N % 32 == 0:
+        I = N // 2
+        g, u = matmul_nt(x, wdense[:I]), matmul_nt(x, wdense[I:])
+        want = (g / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32) * u
+        out = torch.zeros((M, I), dtype=torch.float32, device="cuda")
+        gemm_skinny(ol, xd, M, "float32", epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, ksplit=1, rnd=0)
+        _assert_close(host(out), want, "float32")
