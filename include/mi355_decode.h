@@ -188,7 +188,8 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *                             staging of the next instead of an rmsnorm launch (default 0: measured neutral)
  *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1)
  * Environment switches read once by the library (A/B runs only): MI_SKINNY_MIN_ROWS (hand-over row count for 16-bit
- * weights, default 9), MI_SKINNY_Q4_MIN_ROWS (set: int4 hands over like 16-bit), MI_GEMM_TILE128 (prefill: always the
+ * weights, default 9), MI_SKINNY_Q4_MIN_ROWS (set: int4 hands over like 16-bit), MI_SKINNY_NO_F32 (set: float32-KV mode
+ * back on the generic VALU kernel), MI_SKINNY_NO_RAGGED_K, MI_GEMM_TILE128 (prefill: always the
  * 128 x 128 tile), MI_GEMM_B_DIRECT (prefill: W fragments straight from global memory). */
 int mi_engine_set_option(mi_engine* e, const char* key, int64_t value);
 /* Blocks until the engine's stream is idle. */
