@@ -370,8 +370,8 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     }
     return MI_OK;
   }
-  if (e->opt_skinny_gemm && c.act == MI_F32 && rows > 16 && gemm_skinny_supported(f.W, c, 16)) {
-    // PagedKVCache mode, more than 16 rows (its prefill): 16 rows per launch of the float32-activation streaming kernel
+  if (e->opt_skinny_gemm && c.act == MI_F32 && rows > 32 && gemm_skinny_supported(f.W, c, 32)) {
+    // PagedKVCache mode, more than 32 rows (its prefill): 32 rows per launch of the float32-activation streaming kernel
     // (each row's arithmetic is that of a decode step, whatever the batch); the generic kernel took 8 rows per pass
     // over W.  A tile GEMM with the three-way split of x is the next step for this mode.
     Prof pr(e, prof);
@@ -379,9 +379,9 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
-    GemvCall c16 = c; c16.M = 16;
-    const size_t need = gemm_skinny_ws_bytes(f.W, c16, 16);
-    const int groups = gemm_skinny_groups(f.W, c16, 16);
+    GemvCall c16 = c; c16.M = 32;
+    const size_t need = gemm_skinny_ws_bytes(f.W, c16, 32);
+    const int groups = gemm_skinny_groups(f.W, c16, 32);
     if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
       MI_HIP(hipStreamSynchronize(e->stream));
       if (need > e->sk_ws_cap) {
@@ -398,9 +398,9 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       }
     }
     const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
-    for (size_t r = 0; r < rows; r += 16) {
+    for (size_t r = 0; r < rows; r += 32) {
       GemvCall cc = c;
-      cc.M = (int)std::min<size_t>(16, rows - r);
+      cc.M = (int)std::min<size_t>(32, rows - r);
       cc.x = x0 + r * (size_t)c.ldx * es_in;
       if (o0) cc.out = o0 + r * (size_t)c.ldo * es_out;
       if (r0) cc.resid = r0 + r * (size_t)c.ldo * es_in;

@@ -83,7 +83,7 @@ struct SkinnyParams {
 template <typename AT, int QB, int MT, bool SWIGLU, bool X32 = false>
 __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT >= 5) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
   constexpr bool Q4 = QB == 4, Q8 = QB == 8, QUANT = QB != 0;
-  static_assert(!X32 || (QB == 0 && MT == 1), "float32 activations: dense weights, 16-row instantiation");
+  static_assert(!X32 || (QB == 0 && MT <= 2), "float32 activations: dense weights, 16- and 32-row instantiations");
   using XT = typename std::conditional<X32, float, AT>::type;
   constexpr int NIMG = X32 ? 3 : 1;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
@@ -587,7 +587,7 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.act == MI_F32) {
     static const bool x32_ok = getenv("MI_SKINNY_NO_F32") == nullptr;
     const int n32 = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
-    return x32_ok && W.wk == WK_BF16 && rows >= 1 && rows <= 16 && W.K % 32 == 0 && c.ldx % 4 == 0 && n32 % 16 == 0 &&
+    return x32_ok && W.wk == WK_BF16 && rows >= 1 && rows <= 32 && W.K % 32 == 0 && c.ldx % 4 == 0 && n32 % 16 == 0 &&
            W.lora_b[0] == nullptr && W.lora_b[1] == nullptr;
   }
   if (c.rnd != RND_NONE) return false;
@@ -648,12 +648,14 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   if (c.act == MI_F32) {
     p.sq_out = nullptr; p.sq_in = nullptr;
     auto launch32 = [&](auto kern) -> int {
-      const size_t lds = 2 * (size_t)3 * 16 * 512;
+      const size_t lds = 2 * (size_t)3 * 16 * pl.mt * 512;
+      MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 32 * 512));
       hipLaunchKernelGGL(kern, dim3(grid), dim3(SK_NW * 64), lds, st, p);
       MI_HIP(hipGetLastError());
       return MI_OK;
     };
-    return sw ? launch32(skinny_kernel<bf16, 0, 1, true, true>) : launch32(skinny_kernel<bf16, 0, 1, false, true>);
+    if (pl.mt == 1) return sw ? launch32(skinny_kernel<bf16, 0, 1, true, true>) : launch32(skinny_kernel<bf16, 0, 1, false, true>);
+    return sw ? launch32(skinny_kernel<bf16, 0, 2, true, true>) : launch32(skinny_kernel<bf16, 0, 2, false, true>);
   }
   return c.act == MI_BF16 ? launch_at<bf16>(p, qb, sw, pl.mt, grid, st) : launch_at<f16>(p, qb, sw, pl.mt, grid, st);
 }

@@ -282,7 +282,7 @@ def test_swiglu_above_64_rows(act, kind, M):
     _assert_close(host(out), want, act)
 
 
-@pytest.mark.parametrize("M,N,K,ksplit", [(1, 80, 128, 1), (8, 256, 4608, 0), (16, 144, 384, 3)])
+@pytest.mark.parametrize("M,N,K,ksplit", [(1, 80, 128, 1), (8, 256, 4608, 0), (16, 144, 384, 3), (27, 256, 1024, 2)])
 @pytest.mark.parametrize("rnd", [L.RND_NONE, L.RND_BF16])
 def test_float32_activations_on_bf16_weights(M, N, K, ksplit, rnd):
     """PagedKVCache mode: float32 activations, 16-bit weights.  x = hi + mid + lo exactly, three MFMAs per
