@@ -76,14 +76,14 @@ struct SkinnyParams {
 };
 
 // QB: 0 = dense 16-bit weights, 4 / 8 = MLX-affine int4 / int8 codes (group 64)
-// X32: float32 activations (the PagedKVCache mode of a 16-bit model): x is split exactly into three 16-bit
+// X32: float32 activations (the PagedKVCache mode of a bf16 model; dense, int4 and int8 weights): x is split exactly into three 16-bit
 // terms, x = hi + mid + lo, staged as three fragment images and multiplied by three MFMAs per weight fragment -- every
 // product is exact in the float32 accumulator, so the result is a float32 dot product in another summation order.
 // Outputs stay float32 with the run-time logical rounding `rnd` (layer 0 of that mode still rounds like the model).
 template <typename AT, int QB, int MT, bool SWIGLU, bool X32 = false>
-__global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT >= 5) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
+__global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT >= 5 || (X32 && QB == 8 && MT == 2)) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
   constexpr bool Q4 = QB == 4, Q8 = QB == 8, QUANT = QB != 0;
-  static_assert(!X32 || (QB == 0 && MT <= 2), "float32 activations: dense weights, 16- and 32-row instantiations");
+  static_assert(!X32 || MT <= 2, "float32 activations: 16- and 32-row instantiations");
   using XT = typename std::conditional<X32, float, AT>::type;
   constexpr int NIMG = X32 ? 3 : 1;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       P = (kb * 2 + t) * 4 + gg;
     }
     woff[i] = (P * MB + (m ^ ((P & 7) << 1))) * 16;
-    sxoff[i] = FRAG + ((k8l >> 3) * MB + m) * 4;
+    sxoff[i] = NIMG * FRAG + ((k8l >> 3) * MB + m) * 4;
     xk[i] = k8l * 8;
     xm[i] = m < p.M;
     xmi[i] = m;
@@ -197,6 +197,24 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           const float r1 = xf[j] - (float)hi[j];
           mid[j] = (AT)r1;
           lo[j] = (AT)(r1 - (float)mid[j]);
+        }
+        if constexpr (QUANT) {                   // sum(x) per 64-group in float32; int4: nibble order inside the piece
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum += xf[j];
+          sum = lane8_sum(sum);
+          if ((tid & 7) == 0) *(float*)(buf + sxoff[i]) = sum;
+          if constexpr (Q4) {
+            AT th[8], tm[8], tl[8];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              th[2 * qd] = hi[qd]; th[2 * qd + 1] = hi[qd + 4];
+              tm[2 * qd] = mid[qd]; tm[2 * qd + 1] = mid[qd + 4];
+              tl[2 * qd] = lo[qd]; tl[2 * qd + 1] = lo[qd + 4];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = th[j]; mid[j] = tm[j]; lo[j] = tl[j]; }
+          }
         }
         *(u32x4*)(buf + woff[i]) = *(const u32x4*)hi;
         *(u32x4*)(buf + FRAG + woff[i]) = *(const u32x4*)mid;
@@ -256,14 +274,23 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int pb = (i * 2) * 4 * MB + mt * 16;
-        const u32x4 af0 = *(const u32x4*)(cur + lane_off[0] + pb * 16);
-        const u32x4 af1 = *(const u32x4*)(cur + lane_off[1] + (pb + 4 * MB) * 16);
-        const f32x4 sxv = *(const f32x4*)(cur + FRAG + (i * MB + mt * 16 + g * 4) * 4);
+        const f32x4 sxv = *(const f32x4*)(cur + NIMG * FRAG + (i * MB + mt * 16 + g * 4) * 4);
+        f32x4 dq[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) dq[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) {
+          const u32x4 af0 = *(const u32x4*)(cur + img * FRAG + lane_off[0] + pb * 16);
+          const u32x4 af1 = *(const u32x4*)(cur + img * FRAG + lane_off[1] + (pb + 4 * MB) * 16);
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            dq[a] = mfma16<AT>(af0, wq[a][0], dq[a]);
+            dq[a] = mfma16<AT>(af1, wq[a][1], dq[a]);
+          }
+        }
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          d = mfma16<AT>(af0, wq[a][0], d);
-          d = mfma16<AT>(af1, wq[a][1], d);
+          const f32x4 d = dq[a];
           acc[a][mt].x = fmaf(sc[a], d.x, fmaf(bb[a], sxv.x, acc[a][mt].x));
           acc[a][mt].y = fmaf(sc[a], d.y, fmaf(bb[a], sxv.y, acc[a][mt].y));
           acc[a][mt].z = fmaf(sc[a], d.z, fmaf(bb[a], sxv.z, acc[a][mt].z));
@@ -306,14 +333,23 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int pb = ((i * 2 + sg) * 2) * 4 * MB + mt * 16;
-          const u32x4 af0 = *(const u32x4*)(cur + lane_off[0] + pb * 16);
-          const u32x4 af1 = *(const u32x4*)(cur + lane_off[1] + (pb + 4 * MB) * 16);
-          const f32x4 sxv = *(const f32x4*)(cur + FRAG + ((i * 2 + sg) * MB + mt * 16 + g * 4) * 4);
+          const f32x4 sxv = *(const f32x4*)(cur + NIMG * FRAG + ((i * 2 + sg) * MB + mt * 16 + g * 4) * 4);
+          f32x4 dq[NA];
+#pragma unroll
+          for (int a = 0; a < NA; ++a) dq[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int img = 0; img < NIMG; ++img) {
+            const u32x4 af0 = *(const u32x4*)(cur + img * FRAG + lane_off[0] + pb * 16);
+            const u32x4 af1 = *(const u32x4*)(cur + img * FRAG + lane_off[1] + (pb + 4 * MB) * 16);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+              dq[a] = mfma16<AT>(af0, wq[a][0], dq[a]);
+              dq[a] = mfma16<AT>(af1, wq[a][1], dq[a]);
+            }
+          }
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            d = mfma16<AT>(af0, wq[a][0], d);
-            d = mfma16<AT>(af1, wq[a][1], d);
+            const f32x4 d = dq[a];
             acc[a][mt].x = fmaf(sc[a], d.x, fmaf(bb[a], sxv.x, acc[a][mt].x));
             acc[a][mt].y = fmaf(sc[a], d.y, fmaf(bb[a], sxv.y, acc[a][mt].y));
             acc[a][mt].z = fmaf(sc[a], d.z, fmaf(bb[a], sxv.z, acc[a][mt].z));
@@ -587,7 +623,8 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.act == MI_F32) {
     static const bool x32_ok = getenv("MI_SKINNY_NO_F32") == nullptr;
     const int n32 = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
-    return x32_ok && W.wk == WK_BF16 && rows >= 1 && rows <= 32 && W.K % 32 == 0 && c.ldx % 4 == 0 && n32 % 16 == 0 &&
+    const bool wok = W.wk == WK_BF16 || (W.group == 64 && ((W.wk == WK_Q4_BF16 && W.K % 128 == 0) || (W.wk == WK_Q8_BF16 && W.K % 64 == 0)));
+    return x32_ok && wok && rows >= 1 && rows <= 32 && W.K % 32 == 0 && c.ldx % 4 == 0 && n32 % 16 == 0 &&
            W.lora_b[0] == nullptr && W.lora_b[1] == nullptr;
   }
   if (c.rnd != RND_NONE) return false;
@@ -648,14 +685,19 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   if (c.act == MI_F32) {
     p.sq_out = nullptr; p.sq_in = nullptr;
     auto launch32 = [&](auto kern) -> int {
-      const size_t lds = 2 * (size_t)3 * 16 * pl.mt * 512;
-      MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 32 * 512));
+      const size_t lds = 2 * ((size_t)3 * 16 * pl.mt * 512 + (qb ? 16 * pl.mt * 16 : 0));
+      MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 32 * 512 + 32 * 16)));
       hipLaunchKernelGGL(kern, dim3(grid), dim3(SK_NW * 64), lds, st, p);
       MI_HIP(hipGetLastError());
       return MI_OK;
     };
-    if (pl.mt == 1) return sw ? launch32(skinny_kernel<bf16, 0, 1, true, true>) : launch32(skinny_kernel<bf16, 0, 1, false, true>);
-    return sw ? launch32(skinny_kernel<bf16, 0, 2, true, true>) : launch32(skinny_kernel<bf16, 0, 2, false, true>);
+#define GO32(QBV) do { \
+      if (pl.mt == 1) return sw ? launch32(skinny_kernel<bf16, QBV, 1, true, true>) : launch32(skinny_kernel<bf16, QBV, 1, false, true>); \
+      return sw ? launch32(skinny_kernel<bf16, QBV, 2, true, true>) : launch32(skinny_kernel<bf16, QBV, 2, false, true>); } while (0)
+    if (qb == 4) GO32(4);
+    if (qb == 8) GO32(8);
+    GO32(0);
+#undef GO32
   }
   return c.act == MI_BF16 ? launch_at<bf16>(p, qb, sw, pl.mt, grid, st) : launch_at<f16>(p, qb, sw, pl.mt, grid, st);
 }
