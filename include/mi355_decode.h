@@ -31,6 +31,12 @@
 extern "C" {
 #endif
 
+/* ABI guard.  mi_abi_version() returns MI_ABI_VERSION of the library that was loaded; both parameter structs begin with
+ * `struct_size`, which the caller sets to sizeof() of ITS definition -- a binding generated from another version of this
+ * header (a shorter mi_sample_params would make the library read pointers past its end) is refused with MI_ERR_INVALID
+ * by mi_engine_create / mi_decode_sample / mi_step_enqueue(_rows) / mi_score_tokens instead of being read. */
+#define MI_ABI_VERSION 2
+
 #define MI_OK 0
 #define MI_ERR_INVALID (-1)
 #define MI_ERR_NOTFOUND (-2)
@@ -56,6 +62,7 @@ typedef struct mi_kv mi_kv;         /* opaque; replaces List[PagedKVCache] from 
 
 /* ModelArgs (llama.py:15-46 / mlx-lm qwen3 ModelArgs) + config.json["quantization"] (utils.py:679-690) */
 typedef struct mi_model_desc {
+  uint32_t struct_size;      /* = sizeof(mi_model_desc) of the caller's header (ABI guard) */
   int32_t arch;              /* MI_ARCH_* */
   int32_t hidden_size;
   int32_t num_layers;
@@ -76,6 +83,7 @@ typedef struct mi_model_desc {
 
 /* arguments of the `sample` closure (utils.py:345-364) + top_p_sampling (sample_utils.py:3-38) */
 typedef struct mi_sample_params {
+  uint32_t struct_size;      /* = sizeof(mi_sample_params) of the caller's header (ABI guard) */
   float temperature;         /* 0 -> greedy argmax (utils.py:352-353) */
   float top_p;               /* 0<top_p<1 -> nucleus (utils.py:355-356), else plain categorical */
   int32_t n_logit_bias;      /* logit_bias dict (utils.py:346-349) */
@@ -197,6 +205,7 @@ int mi_engine_sync(mi_engine* e);
 
 const char* mi_last_error(void);
 const char* mi_version(void);
+int mi_abi_version(void);                  /* MI_ABI_VERSION of the loaded library */
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ MI_F32, MI_BF16, MI_F16, MI_U32 = 0, 1, 2, 3
 MI_KV_MODEL = -1
 MI_ARCH_LLAMA, MI_ARCH_QWEN3 = 0, 1
 MI_MAX_TOP_LOGPROBS = 20
+MI_ABI_VERSION = 2
 WK = {"f32": 0, "bf16": 1, "f16": 2, "q4_f32": 3, "q4_bf16": 4, "q4_f16": 5, "q8_f32": 6, "q8_bf16": 7, "q8_f16": 8}
 RND_NONE, RND_BF16, RND_F16 = 0, 1, 2
 PRO_NONE, PRO_NORM = 0, 1
@@ -28,6 +29,7 @@ _ERRORS = {-1: ValueError, -2: FileNotFoundError, -3: NotImplementedError, -4: R
 
 class ModelDesc(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("arch", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
         ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("intermediate_size", C.c_int32),
         ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
@@ -38,6 +40,7 @@ class ModelDesc(C.Structure):
 
 class SampleParams(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("temperature", C.c_float), ("top_p", C.c_float), ("n_logit_bias", C.c_int32),
         ("logit_bias_ids", C.POINTER(C.c_int32)), ("logit_bias_values", C.POINTER(C.c_float)),
         ("uniforms", C.POINTER(C.c_float)), ("seed", C.c_uint64), ("top_logprobs", C.c_int32),
@@ -93,6 +96,7 @@ SIGNATURES = {
     "mi_engine_sync": (C.c_int, [_P]),
     "mi_last_error": (C.c_char_p, []),
     "mi_version": (C.c_char_p, []),
+    "mi_abi_version": (C.c_int, []),
     # mi355_ops.h
     "mi_op_gemv": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs)]),
     "mi_op_gemv_uses_mfma": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs)]),
@@ -148,6 +152,9 @@ def lib() -> C.CDLL:
         fn = getattr(handle, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    if handle.mi_abi_version() != MI_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {handle.mi_abi_version()}, this binding expects {MI_ABI_VERSION}: "
+                          "rebuild the library (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = handle
     return _lib
 

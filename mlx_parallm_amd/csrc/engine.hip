@@ -305,8 +305,9 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     // Decode only: a prefill keeps ONE arithmetic whatever the batch around a sequence (the tile GEMM from 32 rows
     // up, 16-row launches below), which tests/test_gpu_fullsize.py holds bit for bit.
     Prof pr(e, prof);
-    const bool handed = sq_was_valid && e->opt_norm_handover && c.pro == PRO_NORM && rows <= 16 && e->sq_src == c.x &&
-                        e->sq_K == f.W.K && c.ldx == f.W.K;
+    // (float32 activations: the split-K kernel neither leaves nor takes the row statistics -- always the norm launch)
+    const bool handed = sq_was_valid && e->opt_norm_handover && c.act != MI_F32 && c.pro == PRO_NORM && rows <= 16 &&
+                        e->sq_src == c.x && e->sq_K == f.W.K && c.ldx == f.W.K;
     c.M = (int)rows;
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {     // (normalises on its own when c.pro says so)
       c.lora_t = e->lora_t; c.lora_t_ld = 128;
@@ -319,7 +320,8 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     }
     const size_t need = gemm_skinny_ws_bytes(f.W, c, rows);
     const int groups = gemm_skinny_groups(f.W, c, rows);
-    const bool produce = e->opt_norm_handover && c.epi == EPI_RESID && rows <= 16 && groups <= 4096 && c.ldo == f.W.N;
+    const bool produce = e->opt_norm_handover && c.act != MI_F32 && c.epi == EPI_RESID && rows <= 16 && groups <= 4096 &&
+                         c.ldo == f.W.N;
     if (produce) {
       if (!e->d_sq) MI_HIP(hipMalloc(&e->d_sq, (size_t)4096 * 16 * sizeof(float)));
       c.sq_out = e->d_sq;
@@ -379,9 +381,17 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
+    // workspace for every chunk size that is launched below: full 32-row chunks and the tail, whose plan (tile rows,
+    // K split) is made for ITS row count and can need more partial-tile space than the 32-row plan
     GemvCall c16 = c; c16.M = 32;
-    const size_t need = gemm_skinny_ws_bytes(f.W, c16, 32);
-    const int groups = gemm_skinny_groups(f.W, c16, 32);
+    const size_t tail = rows % 32;
+    size_t need = gemm_skinny_ws_bytes(f.W, c16, 32);
+    int groups = gemm_skinny_groups(f.W, c16, 32);
+    if (tail) {
+      GemvCall ct = c; ct.M = (int)tail;
+      need = std::max(need, gemm_skinny_ws_bytes(f.W, ct, tail));
+      groups = std::max(groups, gemm_skinny_groups(f.W, ct, tail));
+    }
     if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
       MI_HIP(hipStreamSynchronize(e->stream));
       if (need > e->sk_ws_cap) {
@@ -635,8 +645,17 @@ int upload_tokens(mi_engine* e, const int32_t* tokens, int B, int L) {
   return MI_OK;
 }
 
+// ABI guard (mi355_decode.h): a binding built against another layout of the struct is refused, never read
+int check_params(const mi_sample_params* sp) {
+  if (sp != nullptr && sp->struct_size != sizeof(mi_sample_params))
+    return fail(MI_ERR_INVALID, "mi_sample_params.struct_size = " + std::to_string(sp->struct_size) + ", this library (ABI " +
+                                    std::to_string(MI_ABI_VERSION) + ") expects " + std::to_string(sizeof(mi_sample_params)) +
+                                    ": the binding was generated from another version of mi355_decode.h");
+  return MI_OK;
+}
+
 int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* forced = nullptr) {
-  mi_sample_params def{}; def.temperature = 0.f; def.top_p = 1.f;
+  mi_sample_params def{}; def.struct_size = sizeof(def); def.temperature = 0.f; def.top_p = 1.f;
   if (!sp) sp = &def;
   hipStream_t st = e->stream;
   if (sp->n_logit_bias > 0) {
@@ -679,10 +698,14 @@ int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* f
 extern "C" {
 
 const char* mi_last_error(void) { return g_err.c_str(); }
-const char* mi_version(void) { return "mi355_decode 0.1 (gfx950)"; }
+const char* mi_version(void) { return "mi355_decode 0.2 (gfx950)"; }
+int mi_abi_version(void) { return MI_ABI_VERSION; }
 
 int mi_engine_create(const mi_model_desc* desc, int device, mi_engine** out) {
   if (!desc || !out) return fail(MI_ERR_INVALID, "null argument");
+  if (desc->struct_size != sizeof(mi_model_desc))
+    return fail(MI_ERR_INVALID, "mi_model_desc.struct_size = " + std::to_string(desc->struct_size) + ", this library (ABI " +
+                                    std::to_string(MI_ABI_VERSION) + ") expects " + std::to_string(sizeof(mi_model_desc)));
   const mi_model_desc& d = *desc;
   if (d.arch != MI_ARCH_LLAMA && d.arch != MI_ARCH_QWEN3) return fail(MI_ERR_UNSUPPORTED, "unsupported arch");
   if (d.hidden_size <= 0 || d.num_layers <= 0 || d.num_heads <= 0 || d.num_kv_heads <= 0 || d.head_dim <= 0 ||
@@ -963,6 +986,7 @@ int mi_forward(mi_engine* e, mi_kv* kv, const int32_t* tokens, int B, int L, flo
 
 int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_t* targets, int B, int L,
                     const mi_sample_params* sp, float* logprob_out, int32_t* topk_ids, float* topk_logprobs) {
+  MI_TRY(check_params(sp));
   MI_TRY(check_call(e, kv, B, L));
   if (!tokens || !targets || !logprob_out) return fail(MI_ERR_INVALID, "null argument");
   const size_t R = (size_t)B * L;
@@ -992,6 +1016,7 @@ int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_
 
 int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L, const mi_sample_params* sp,
                     int64_t* ticket) {
+  MI_TRY(check_params(sp));
   MI_TRY(check_call(e, kv, B, L));
   if (!ticket) return fail(MI_ERR_INVALID, "null ticket");
   if (!tokens_in && L != 1) return fail(MI_ERR_INVALID, "device-resident token feed needs L == 1");
@@ -1021,6 +1046,7 @@ int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, in
 int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, const int32_t* tokens_in, int L,
                          const mi_sample_params* sp, int64_t* ticket) {
   if (!e || !kv || !rows) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(check_params(sp));
   if (n < 1 || n > kv->B) return fail(MI_ERR_INVALID, "mi_step_enqueue_rows: n must be in [1, batch of the kv]");
   for (int i = 0; i < n; ++i) {
     if (rows[i] < 0 || rows[i] >= kv->B) return fail(MI_ERR_INVALID, "mi_step_enqueue_rows: row out of range");

@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -576,10 +577,14 @@ template <typename AT, int QB, int MT, bool SWIGLU>
 int launch_k(const SkinnyParams& p, int grid, hipStream_t st) {
   auto kern = skinny_kernel<AT, QB, MT, SWIGLU>;
   const size_t lds = 2 * ((size_t)16 * MT * 512 + (QB ? 16 * MT * 16 : 0));
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the opt-in belongs to the kernel object of the CURRENT device (one engine per GPU may live in one process:
+  // server --devices), and several scheduler threads launch concurrently: one flag per device, set after the call
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
     MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 512 + 128 * 16)));
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(SK_NW * 64), lds, st, p);
   MI_HIP(hipGetLastError());

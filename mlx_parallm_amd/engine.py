@@ -52,6 +52,7 @@ class SampleArgs:
                  uniforms: Optional[Sequence[float]] = None, seed: int = 0, top_logprobs: int = 0,
                  logprobs_at_temperature: bool = False):
         self.c = L.SampleParams()
+        self.c.struct_size = C.sizeof(L.SampleParams)
         self.c.temperature = float(temp)
         self.c.top_p = float(top_p)
         self.c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -161,6 +162,7 @@ class Engine:
             raise ValueError(f"Model type {config['model_type']} not supported.")    # utils.py:62-65
         nh = int(config["num_attention_heads"])
         d = L.ModelDesc()
+        d.struct_size = C.sizeof(L.ModelDesc)
         d.arch = L.MI_ARCH_QWEN3 if mt == "qwen3" else L.MI_ARCH_LLAMA
         d.hidden_size = int(config["hidden_size"])
         d.num_layers = int(config["num_hidden_layers"])

@@ -919,7 +919,8 @@ def _request_params(req: AnyRequest) -> Tuple[int, float, float]:
 
 
 def _submit(state: ServerState, tok: TokenizerWrapper, text: str, req: AnyRequest, on_delta: Optional[Callable] = None):
-    """Queue one sequence; -> (future resolving to (text, n_prompt, n_completion, finish_reason), n_prompt)."""
+    """Queue one sequence; -> (future resolving to (text, n_prompt, n_completion, finish_reason), n_prompt, sequence).
+    ``sequence.cancel()`` frees its KV slot when the caller gives up (timeout, client disconnect)."""
     loop = asyncio.get_running_loop()
     fut: asyncio.Future = loop.create_future()
     ids = _ids_of(tok, text)[0]
@@ -936,10 +937,10 @@ def _submit(state: ServerState, tok: TokenizerWrapper, text: str, req: AnyReques
             loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(result))
 
     try:
-        state.scheduler.submit(ids, max_tokens, temp, top_p, sink)
+        seq = state.scheduler.submit(ids, max_tokens, temp, top_p, sink)
     except ValueError as e:
         raise HTTPException(status_code=400, detail=str(e))
-    return fut, len(ids)
+    return fut, len(ids), seq
 
 
 async def _scheduled_response(state: ServerState, request: AnyRequest, tok: TokenizerWrapper, model_name: str):
@@ -952,11 +953,18 @@ async def _scheduled_response(state: ServerState, request: AnyRequest, tok: Toke
         text = prompt_text_of(request, tok)
     except Exception as e:
         raise HTTPException(status_code=500, detail=f"Error processing request: {e}")
-    futs = [_submit(state, tok, text, request)[0] for _ in range(n)]
+    subs = [_submit(state, tok, text, request) for _ in range(n)]
+    futs = [sub[0] for sub in subs]
     try:
         results = await asyncio.wait_for(asyncio.gather(*futs), timeout=state.config.request_timeout_seconds)
     except asyncio.TimeoutError:
+        for sub in subs:
+            sub[2].cancel()                  # abandoned sequences must not keep their KV slots until max_tokens
         raise HTTPException(status_code=504, detail="Request processing timed out.")
+    except asyncio.CancelledError:           # the client went away
+        for sub in subs:
+            sub[2].cancel()
+        raise
     if any(r[3] == "error" for r in results):
         raise HTTPException(status_code=500, detail="Error processing request: generation failed")
     usage = CompletionUsage(prompt_tokens=results[0][1], completion_tokens=sum(r[2] for r in results),
@@ -972,12 +980,16 @@ async def _scheduled_response(state: ServerState, request: AnyRequest, tok: Toke
 async def _scheduled_events(state: ServerState, request: AnyRequest, tok: TokenizerWrapper) -> AsyncGenerator[Tuple[Optional[str], Optional[str]], None]:
     """(delta, finish_reason) events of one sequence, as they are produced."""
     q: asyncio.Queue = asyncio.Queue()
-    _submit(state, tok, prompt_text_of(request, tok), request, on_delta=lambda d, r: q.put_nowait((d, r)))
-    while True:
-        delta, reason = await q.get()
-        yield delta, reason
-        if reason is not None:
-            return
+    seq = _submit(state, tok, prompt_text_of(request, tok), request, on_delta=lambda d, r: q.put_nowait((d, r)))[2]
+    try:
+        while True:
+            delta, reason = await q.get()
+            yield delta, reason
+            if reason is not None:
+                return
+    finally:
+        if seq.finished is None:             # generator closed early: the client disconnected mid-stream
+            seq.cancel()
 
 
 async def _scheduled_chat_stream(state: ServerState, request: ChatCompletionRequest, tok: TokenizerWrapper) -> AsyncGenerator[str, None]:

@@ -52,6 +52,12 @@ class Sequence:
         self.finished: Optional[str] = None
         self.last_token = -1
         self.t_submit = time.perf_counter()
+        self.cancelled = False
+
+    def cancel(self) -> None:
+        """Ask the scheduler to drop this sequence (client gone / request timed out): it stops taking decode steps
+        at the next step boundary, its slot is released and its sink gets finish_reason "cancelled"."""
+        self.cancelled = True
 
 
 class ContinuousScheduler:
@@ -69,6 +75,7 @@ class ContinuousScheduler:
         self.cv = threading.Condition()
         self.engine_mutex = threading.Lock()
         self._waiters = 0
+        self._step_pending = False         # a step that reads the device-resident token feed is enqueued but not read
         self._stop = False
         self._thread: Optional[threading.Thread] = None
         self._seed = int.from_bytes(os.urandom(4), "little")
@@ -112,11 +119,23 @@ class ContinuousScheduler:
             self.s = s
 
         def __enter__(self):
-            with self.s.cv:
-                self.s._waiters += 1
-                self.s.cv.notify_all()
-            self.s.engine_mutex.acquire()
-            return self
+            # A borrower overwrites the engine's device-resident token feed (d_next / last_n), so it may only get
+            # the engine when no enqueued step is still going to read that feed.  The scheduler publishes that in
+            # _step_pending (written while it holds the mutex); once _waiters > 0 it drains before every release.
+            s = self.s
+            with s.cv:
+                s._waiters += 1
+                s.cv.notify_all()
+            while True:
+                with s.cv:
+                    while s._step_pending and not s._stop:
+                        s.cv.wait(timeout=0.05)
+                s.engine_mutex.acquire()
+                with s.cv:
+                    clear = not s._step_pending
+                if clear:
+                    return self
+                s.engine_mutex.release()
 
         def __exit__(self, *exc):
             with self.s.cv:
@@ -182,8 +201,20 @@ class ContinuousScheduler:
 
     def _release_finished(self) -> None:
         for i, s in enumerate(self.slots):
+            if s is not None and s.cancelled and not s.finished:
+                s.finished = "cancelled"
+                self._emit(s, None, "cancelled")
             if s is not None and s.finished:
                 self.slots[i] = None
+
+    def _drop_cancelled_pending(self) -> None:
+        with self.cv:
+            gone = [s for s in self.pending if s.cancelled]
+            for s in gone:
+                self.pending.remove(s)
+        for s in gone:
+            s.finished = "cancelled"
+            self._emit(s, None, "cancelled")
 
     def _run(self) -> None:
         eng = self.model.engine
@@ -200,6 +231,9 @@ class ContinuousScheduler:
                         self._on_token(s, int(t))
                 inflight = None
                 sp_keep.clear()
+            with self.cv:
+                self._step_pending = False
+                self.cv.notify_all()
 
         while True:
             with self.cv:
@@ -213,7 +247,10 @@ class ContinuousScheduler:
             try:
                 with self.engine_mutex:
                     # ---- admissions: one prefill per new sequence, on its own row
+                    if inflight is not None and any(s.cancelled and not s.finished for s in inflight[1]):
+                        drain()                              # the row set changes: finish the step in flight first
                     self._release_finished()
+                    self._drop_cancelled_pending()
                     while True:
                         with self.cv:
                             free = [i for i, s in enumerate(self.slots) if s is None]
@@ -260,9 +297,15 @@ class ContinuousScheduler:
                         must_yield = self._waiters > 0
                     if must_yield:
                         drain()
+                    with self.cv:                            # (still inside the mutex: see _Borrow.__enter__)
+                        self._step_pending = inflight is not None
+                        self.cv.notify_all()
             except Exception as e:          # engine failure: fail every sequence, keep the thread alive
                 log.exception("scheduler step failed")
                 inflight = None
+                with self.cv:
+                    self._step_pending = False
+                    self.cv.notify_all()
                 for i, s in enumerate(self.slots):
                     if s is not None and not s.finished:
                         s.finished = "error"

@@ -152,7 +152,8 @@ def build_tiny_model(dst, *, seed: int = 0, model_type: str = "llama", hidden_si
                      tie_word_embeddings: bool = True, quantize_model: bool = True, q_bits: int = 4,
                      q_group_size: int = 64, vocab_size: Optional[int] = None, dtype: str = "float32",
                      head_dim: Optional[int] = None, with_tokenizer: bool = True, norm_jitter: float = 0.0,
-                     weight_std: Optional[float] = None) -> Dict[str, Any]:
+                     weight_std: Optional[float] = None, rms_norm_eps: float = 1e-6,
+                     max_position_embeddings: int = 4096) -> Dict[str, Any]:
     """scripts/build_tiny_model.py:104-160.  Returns the config dict it wrote."""
     from safetensors.torch import save_file
 
@@ -167,7 +168,8 @@ def build_tiny_model(dst, *, seed: int = 0, model_type: str = "llama", hidden_si
     cfg = build_config(model_type=model_type, vocab_size=vocab_size, hidden_size=hidden_size,
                        num_hidden_layers=layers, intermediate_size=intermediate_size,
                        num_attention_heads=heads, num_key_value_heads=kv_heads, rope_theta=rope_theta,
-                       tie_word_embeddings=tie_word_embeddings, quantization=quant, head_dim=head_dim)
+                       tie_word_embeddings=tie_word_embeddings, quantization=quant, head_dim=head_dim,
+                       rms_norm_eps=rms_norm_eps, max_position_embeddings=max_position_embeddings)
     w = init_weights(cfg, seed=seed, dtype=dtype, norm_jitter=norm_jitter, weight_std=weight_std)
     if quantize_model:
         w = quantize_weights(w, q_group_size, q_bits)

@@ -64,79 +64,99 @@ def get_model_path(path_or_hf_repo: str, revision: Optional[str] = None) -> Path
     return model_path
 
 
-# --------- LRU caches (utils.py:137-194) ---------
-class _LRUCache:
-    def __init__(self, max_size: int = 2048):
-        self.max_size = max_size
-        self._store: "OrderedDict[str, Any]" = OrderedDict()
+# --------- host-side memoisation (role of utils.py:137-194: tokenisation and chat templating are re-done for
+# identical texts by every request of a sampling group, so both are memoised per tokenizer) ---------
+class _BoundedMemo:
+    """Least-recently-used memo of at most ``limit`` entries.  ``fetch(key, make)`` returns the stored value or
+    stores ``make()``; keys are hashable tuples (no string formatting on the hot path)."""
 
-    def get(self, key: str):
-        if key in self._store:
-            self._store.move_to_end(key)
-            return self._store[key]
-        return None
+    __slots__ = ("limit", "_entries")
 
-    def set(self, key: str, value: Any):
-        self._store[key] = value
-        self._store.move_to_end(key)
-        if len(self._store) > self.max_size:
-            self._store.popitem(last=False)
+    def __init__(self, limit: int):
+        self.limit = int(limit)
+        self._entries: "OrderedDict[Any, Any]" = OrderedDict()
+
+    def __len__(self) -> int:
+        return len(self._entries)
+
+    def peek(self, key):
+        hit = self._entries.get(key)
+        if hit is not None:
+            self._entries.move_to_end(key)
+        return hit
+
+    def put(self, key, value) -> None:
+        entries = self._entries
+        entries[key] = value
+        entries.move_to_end(key)
+        while len(entries) > self.limit:
+            entries.popitem(last=False)
+
+    def fetch(self, key, make: Callable[[], Any]):
+        hit = self.peek(key)
+        if hit is None:
+            hit = make()
+            self.put(key, hit)
+        return hit
 
 
-_encode_lru = _LRUCache(max_size=4096)
-_chat_template_lru = _LRUCache(max_size=2048)
+_token_memo = _BoundedMemo(4096)
+_template_memo = _BoundedMemo(2048)
+
+
+def _tokenizer_tag(tokenizer) -> int:
+    return id(getattr(tokenizer, "_tokenizer", tokenizer))
 
 
 def encode_cached(tokenizer: TokenizerWrapper, text: str) -> List[int]:
-    key = f"tok:{id(tokenizer._tokenizer)}:{text}"
-    val = _encode_lru.get(key)
-    if val is not None:
-        return val
-    enc = tokenizer.encode(text)
-    _encode_lru.set(key, enc)
-    return enc
+    """``tokenizer.encode(text)``, memoised per (tokenizer, text)  (reference: utils.py:163-170)."""
+    return _token_memo.fetch((_tokenizer_tag(tokenizer), text), lambda: tokenizer.encode(text))
 
 
-def _messages_cache_key(messages: List[Dict[str, Any]]) -> str:
-    minimal = [{"role": m.get("role"), "content": m.get("content")} for m in messages]
-    return json.dumps(minimal, sort_keys=True, separators=(",", ":"))
+def _conversation_key(messages: List[Dict[str, Any]]) -> Tuple:
+    """Only role and content decide the rendered prompt; anything unhashable (content parts) is keyed by its
+    canonical JSON."""
+    def atom(v):
+        return v if isinstance(v, (str, int, float, bool, type(None))) else json.dumps(v, sort_keys=True, default=str)
+    return tuple((atom(m.get("role")), atom(m.get("content"))) for m in messages)
 
 
 def apply_chat_template_cached(tokenizer: TokenizerWrapper, messages: List[Dict[str, Any]], *,
                                add_generation_prompt: bool = True) -> str:
-    key = f"cht:{id(tokenizer._tokenizer)}:{'1' if add_generation_prompt else '0'}:{_messages_cache_key(messages)}"
-    val = _chat_template_lru.get(key)
-    if val is not None:
-        return val
-    text = tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=add_generation_prompt)
-    _chat_template_lru.set(key, text)
-    return text
+    """The rendered chat prompt, memoised per (tokenizer, flag, conversation)  (reference: utils.py:178-194)."""
+    key = (_tokenizer_tag(tokenizer), bool(add_generation_prompt), _conversation_key(messages))
+    return _template_memo.fetch(key, lambda: tokenizer.apply_chat_template(
+        messages, tokenize=False, add_generation_prompt=add_generation_prompt))
 
 
-# --------- KV pool (utils.py:199-226) ---------
+# --------- KV pool (role of utils.py:199-226) ---------
 class _KVPool:
-    """Pool of per-layer cache lists keyed by (head_dim, kv_heads, batch_size); a reused list is
-    ``reset`` (offsets to zero, device buffers kept)."""
+    """Hands out the per-layer cache list of a batch shape and keeps it for the next batch of that shape: the
+    device buffers behind a list (one ``mi_kv``) survive, only the row lengths go back to zero.  Lists are keyed
+    by everything that decides the allocation: head size, kv heads per layer, batch, cache class and KV dtype."""
 
     def __init__(self):
         self._pool: Dict[Tuple, List[BatchedKVCache]] = {}
 
+    @staticmethod
+    def _recycle(caches: List[BatchedKVCache], batch_size: int, step: Optional[int]) -> None:
+        for layer_cache in caches:
+            layer_cache.reset(batch_size)
+            if step is not None:
+                layer_cache.step = step
+
     def get(self, head_dim: int, kv_heads: List[int], batch_size: int, *, step: Optional[int] = None,
             paged: bool = True, kv_dtype: Optional[str] = None) -> List[BatchedKVCache]:
-        kvd = kv_dtype or DEFAULT_KV_DTYPE
-        key = (head_dim, tuple(kv_heads), batch_size, paged, kvd)
-        caches = self._pool.get(key)
-        if caches is None:
-            klass = PagedKVCache if paged else BatchedKVCache
-            caches = make_cache_list(klass, head_dim, kv_heads, batch_size, step)
-            group_of(caches).kv_dtype = kvd if paged else "model"
-            self._pool[key] = caches
-        else:
-            for c in caches:
-                c.reset(batch_size)
-                if step is not None:
-                    c.step = step
-        return caches
+        dtype_name = (kv_dtype or DEFAULT_KV_DTYPE) if paged else "model"
+        key = (int(head_dim), tuple(kv_heads), int(batch_size), bool(paged), dtype_name)
+        pooled = self._pool.get(key)
+        if pooled is not None:
+            self._recycle(pooled, batch_size, step)
+            return pooled
+        fresh = make_cache_list(PagedKVCache if paged else BatchedKVCache, head_dim, kv_heads, batch_size, step)
+        group_of(fresh).kv_dtype = dtype_name
+        self._pool[key] = fresh
+        return fresh
 
     def clear(self):
         for caches in self._pool.values():

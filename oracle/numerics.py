@@ -12,12 +12,19 @@ DTYPES = ("float32", "bfloat16", "float16")
 
 
 def round_bf16(x: np.ndarray) -> np.ndarray:
-    """float32 -> nearest-even bfloat16 -> float32 (NaN kept NaN)."""
+    """float32 -> nearest-even bfloat16 -> float32 (NaN kept NaN).  uint32 arithmetic: the add can only wrap for
+    NaN bit patterns, which are restored afterwards."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    u = x.view(np.uint32)
+    r = (u >> np.uint32(16)) & np.uint32(1)
+    r += np.uint32(0x7FFF)
+    r += u
+    r &= np.uint32(0xFFFF0000)
     out = r.view(np.float32).reshape(x.shape)
-    return np.where(np.isnan(x), x, out).astype(np.float32)
+    nan = (u & np.uint32(0x7FFFFFFF)) > np.uint32(0x7F800000)
+    if nan.any():
+        out[nan.reshape(x.shape)] = x[nan.reshape(x.shape)]
+    return out
 
 
 def round_to(x: np.ndarray, dtype: str) -> np.ndarray:
@@ -46,4 +53,4 @@ def matmul_nt(x: np.ndarray, w: np.ndarray) -> np.ndarray:
     MLX's matmul / quantized_matmul accumulate in fp32; the oracle uses the exactly
     rounded value (fp64 accumulate, one rounding to fp32) so that it is independent of
     any summation order."""
-    return (x.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32)
+    return (np.asarray(x, dtype=np.float64) @ np.asarray(w, dtype=np.float64).T).astype(np.float32)

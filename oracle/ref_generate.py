@@ -98,7 +98,7 @@ def load(model_dir: str, adapter_path: Optional[str] = None, max_pos: int = 4096
 def generate_step(prompts: np.ndarray, model: RefModel, temp: float = 0.0,
                   repetition_penalty: Optional[float] = None, repetition_context_size: int = 20,
                   top_p: float = 1.0, logit_bias=None, cache=None, uniforms_fn=None, paged: bool = True,
-                  return_logits: bool = False) -> Iterator:
+                  return_logits: bool = False, last_only: bool = False) -> Iterator:
     """utils.py:315-427.  Yields (tokens (B,1), probs (B,1)) [+ logits, logprobs if asked].
     ``uniforms_fn(step) -> (B,) uniforms`` supplies the noise for temp>0 (see ref_sample)."""
     if repetition_penalty:
@@ -109,7 +109,7 @@ def generate_step(prompts: np.ndarray, model: RefModel, temp: float = 0.0,
         cache = model.make_cache(B, paged=paged)                                # utils.py:390-394
     step = 0
     while True:
-        logits = model(y, cache=cache)[:, -1, :]                                # utils.py:403-404
+        logits = model(y, cache=cache, last_only=last_only)[:, -1, :]           # utils.py:403-404
         u = uniforms_fn(step) if (temp != 0 and uniforms_fn is not None) else None
         s = sample(logits, temp=temp, top_p=top_p, logit_bias=logit_bias, uniforms=u)
         y = s["tokens"]

@@ -24,6 +24,9 @@ from .numerics import matmul_nt, round_to
 from .ref_quant import dequantize
 
 
+CACHE_F64 = False      # speed only: keep a float64 copy of every weight matrix (make_golden_wide.py sets it)
+
+
 def promote(a: str, b: str) -> str:
     if a == b:
         return a
@@ -46,6 +49,7 @@ class Linear:
     lora_scale: float = 0.0
     lora_dtype: str = "float32"
     _dense_cache: Optional[np.ndarray] = field(default=None, repr=False)
+    _dense64: Optional[np.ndarray] = field(default=None, repr=False)
 
     def dense(self) -> np.ndarray:
         if self.weight is not None:
@@ -55,10 +59,19 @@ class Linear:
                                            self.group_size, self.bits)
         return self._dense_cache
 
+    def dense64(self) -> np.ndarray:
+        """float64 copy of ``dense()`` when CACHE_F64 is on (same values; saves the per-call widening of a
+        production-width matrix in the decode steps of tests/golden/make_golden_wide.py)."""
+        if not CACHE_F64:
+            return self.dense()
+        if self._dense64 is None:
+            self._dense64 = self.dense().astype(np.float64)
+        return self._dense64
+
     def __call__(self, x: np.ndarray, xdt: str):
         """x @ W.T with fp32 accumulation; output dtype = result_type(x, W) (App. A.1)."""
         odt = promote(xdt, self.dtype)
-        y = round_to(matmul_nt(x, self.dense()), odt)
+        y = round_to(matmul_nt(x, self.dense64()), odt)
         if self.lora_a is not None:
             # y + (scale * ((x @ A) @ B)).astype(x.dtype)     (App. A.6)
             zdt = promote(xdt, self.lora_dtype)
@@ -217,13 +230,13 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     odt = promote(qdt, kdt)
     k = np.repeat(k, rep, axis=1).astype(np.float64)
     v = np.repeat(v, rep, axis=1).astype(np.float64)
-    s = np.einsum("bhld,bhsd->bhls", q.astype(np.float64), k) * float(scale)
+    s = np.matmul(q.astype(np.float64), k.transpose(0, 1, 3, 2)) * float(scale)     # (B,H,L,S), float64 sums
     if mask is not None:
         s = s + mask[:, None, :, :].astype(np.float64)
     s = s - s.max(axis=-1, keepdims=True)
     p = np.exp(s)
     p = p / p.sum(axis=-1, keepdims=True)
-    o = np.einsum("bhls,bhsd->bhld", p, v).astype(np.float32)
+    o = np.matmul(p, v).astype(np.float32)
     return round_to(o, odt), odt
 
 
@@ -358,8 +371,13 @@ class RefModel:
         nw, nwdt = self.w["model.norm"]
         return rms_norm(h, hdt, nw, nwdt, cfg.rms_norm_eps)
 
-    def __call__(self, inputs: np.ndarray, cache=None) -> np.ndarray:
+    def __call__(self, inputs: np.ndarray, cache=None, last_only: bool = False) -> np.ndarray:
+        """``last_only``: logits of the last position only, shape (B, 1, V).  The reference computes every
+        position and slices (utils.py:403-404); the head is row-wise, so the values are the same -- this only
+        spares the oracle a (B*L, V) matmul at production widths."""
         h, hdt = self.hidden(inputs, cache)
+        if last_only:
+            h = h[:, -1:, :]
         head = self.w["model.embed_tokens"] if self.cfg.tie_word_embeddings else self.w["lm_head"]
         logits, _ = head(h, hdt)                                          # llama.py:249-252
         return logits

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/wide_*.npz -- oracle outputs at PRODUCTION widths (BASELINE configs 2-5).
+
+The small goldens (make_golden.py) pin the decode path on 64..128-wide models.  These pin it at the real layer
+shapes: Mistral-7B (H 4096, 32 q / 8 kv heads x 128, I 14336, V 32000) and Qwen3-14B (H 5120, 40 / 8 heads x 128 with
+q/k norms, I 17408, V 151936), truncated to 2 decoder blocks so that the NumPy oracle finishes in minutes; bf16, int4
+g64 and int4 + a rank-16 LoRA adapter on q/v; both KV modes (PagedKVCache float32 = the reference's default numerics,
+BatchedKVCache = model dtype); batch 8 with a 1024-token prompt decoded to KV length 1101 (the regime of the bench,
+including the second 256-key round of the split-KV decode attention), plus a batch-32 and a ragged batch-64 case
+(configs 4 and 5).  "parity unpinned": like every golden here these are outputs of the build's own oracle, not of MLX.
+
+Checkpoints are NOT committed: tests/wide_models.py rebuilds them from seeds on either side.  Stored per case: the
+case spec (JSON), and per step the oracle's token ids, chosen-token logprobs, the 8 largest logits with their ids and
+the top1-top2 margin.  Run (about 40 min on 8 cores, < 40 GB):  python tests/golden/make_golden_wide.py [case ...]
+"""
+import json
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import wide_models  # noqa: E402
+from oracle import ref_generate, ref_model  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+MAIN = dict(B=8, L0=1024, steps=77, temp=0.0, top_p=1.0)
+# checkpoint (family, precision, seed) -> runs on it (adapter runs last: apply_adapters edits the weights in place)
+CHECKPOINTS = {
+    ("mistral-7b", "bf16", 11): [
+        dict(name="wide_mistral_bf16_modelkv", paged=False, **MAIN, prompt_seed=101),           # config 2
+        dict(name="wide_mistral_bf16_paged", paged=True, **MAIN, prompt_seed=102),
+    ],
+    ("mistral-7b", "int4", 12): [
+        dict(name="wide_mistral_int4_modelkv", paged=False, **MAIN, prompt_seed=103),
+        dict(name="wide_mistral_int4_paged", paged=True, **MAIN, prompt_seed=104),
+        dict(name="wide_mistral_int4_topp_paged", paged=True, B=8, L0=1024, steps=24, temp=1.0, top_p=0.9,
+             prompt_seed=105),                                                                   # config 3
+        dict(name="wide_mistral_int4_lora_modelkv", paged=False, lora=True, **MAIN, prompt_seed=106),
+        dict(name="wide_mistral_int4_lora_paged", paged=True, lora=True, **MAIN, prompt_seed=107),
+    ],
+    ("qwen3-14b", "bf16", 13): [
+        dict(name="wide_qwen3_bf16_modelkv", paged=False, **MAIN, prompt_seed=108),
+        dict(name="wide_qwen3_bf16_paged", paged=True, **MAIN, prompt_seed=109),
+        dict(name="wide_qwen3_bf16_b32_modelkv", paged=False, B=32, L0=160, steps=6, temp=0.0, top_p=1.0,
+             prompt_seed=110),                                                                   # config 4 (per-GPU shard x4)
+        dict(name="wide_qwen3_bf16_b32_paged", paged=True, B=32, L0=160, steps=6, temp=0.0, top_p=1.0, prompt_seed=111),
+    ],
+    ("qwen3-14b", "int4", 14): [
+        dict(name="wide_qwen3_int4_modelkv", paged=False, **MAIN, prompt_seed=112),
+        dict(name="wide_qwen3_int4_paged", paged=True, **MAIN, prompt_seed=113),
+        dict(name="wide_qwen3_int4_lora_modelkv", paged=False, lora=True, **MAIN, prompt_seed=114),
+        dict(name="wide_qwen3_int4_lora_paged", paged=True, lora=True, **MAIN, prompt_seed=115),
+        dict(name="wide_qwen3_int4_lora_b64_modelkv", paged=False, lora=True, B=64, L0=96, steps=6, temp=0.0,
+             top_p=1.0, ragged=True, prompt_seed=116),                                           # config 5
+        dict(name="wide_qwen3_int4_lora_b64_paged", paged=True, lora=True, B=64, L0=96, steps=6, temp=0.0, top_p=1.0,
+             ragged=True, prompt_seed=117),
+    ],
+}
+ADAPTER_SEED = 77
+
+
+def run_case(ref, cfg, ck, case):
+    t0 = time.time()
+    B, steps = case["B"], case["steps"]
+    prompts = wide_models.prompts_for(case, cfg["vocab_size"])
+    uniforms = np.random.default_rng(case["prompt_seed"] + 1000).random((steps + 2, B)).astype(np.float32)
+    toks, lps, top_ids, top_vals, margins = [], [], [], [], []
+    gen = ref_generate.generate_step(prompts, ref, temp=case["temp"], top_p=case["top_p"], paged=case["paged"],
+                                     uniforms_fn=lambda s: uniforms[s], return_logits=True, last_only=True)
+    for (t, _p, logits, lp), _ in zip(gen, range(steps)):
+        toks.append(t[:, 0])
+        lps.append(lp)
+        order = np.argsort(-logits, axis=-1, kind="stable")[:, :8]
+        top_ids.append(order)
+        tv = np.take_along_axis(logits, order, axis=-1)
+        top_vals.append(tv)
+        margins.append(tv[:, 0] - tv[:, 1])
+    spec = dict(case, family=ck[0], precision=ck[1], model_seed=ck[2], adapter_seed=ADAPTER_SEED)
+    np.savez_compressed(
+        OUT / f"{case['name']}.npz", spec=json.dumps(spec), uniforms=uniforms,
+        tokens=np.stack(toks).astype(np.int32), logprobs=np.stack(lps).astype(np.float32),
+        top_ids=np.stack(top_ids).astype(np.int32), top_vals=np.stack(top_vals).astype(np.float32),
+        margins=np.stack(margins).astype(np.float32))
+    print(f"{case['name']}: {time.time() - t0:.0f} s, min top1-top2 margin {np.min(margins):.5f}, "
+          f"margins <= 0.13: {int((np.stack(margins) <= 0.13).sum())} of {steps * B}", flush=True)
+
+
+def main():
+    only = set(sys.argv[1:])
+    ref_model.CACHE_F64 = True
+    for ck, cases in CHECKPOINTS.items():
+        cases = [c for c in cases if not only or c["name"] in only]
+        if not cases:
+            continue
+        with tempfile.TemporaryDirectory() as d:
+            t0 = time.time()
+            cfg = wide_models.build_checkpoint(d, *ck)
+            ref = ref_generate.load(d, max_pos=wide_models.MAX_POS)
+            print(f"checkpoint {ck}: built + loaded in {time.time() - t0:.0f} s", flush=True)
+            adapted = False
+            for case in cases:
+                if case.get("lora") and not adapted:
+                    ad = Path(d) / "adapter"
+                    wide_models.build_adapter(ad, cfg, ADAPTER_SEED)
+                    ref_generate.apply_adapters(ref.w, cfg["num_hidden_layers"], str(ad))
+                    adapted = True
+                assert bool(case.get("lora")) == adapted, "adapter runs must come last"
+                run_case(ref, cfg, ck, case)
+
+
+if __name__ == "__main__":
+    main()

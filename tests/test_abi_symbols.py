@@ -56,3 +56,45 @@ def test_product_never_imports_the_oracle():
         text = py.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{py} imports the oracle"
     assert "oracle" not in (ROOT / "mlx_parallm_amd" / "csrc" / "Makefile").read_text()
+
+
+def test_struct_size_guard_refuses_a_binding_from_another_header_version():
+    """mi_model_desc / mi_sample_params start with struct_size (ABI guard, mi355_decode.h): a short or stale struct is
+    refused with MI_ERR_INVALID before anything behind it is read -- checked before the device is even looked for."""
+    from mlx_parallm_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.mi_abi_version() == _lib.MI_ABI_VERSION
+    d = _lib.ModelDesc()
+    d.struct_size = C.sizeof(_lib.ModelDesc) - 4
+    h = C.c_void_p()
+    assert lib.mi_engine_create(C.byref(d), 0, C.byref(h)) == -1 and b"struct_size" in lib.mi_last_error()
+    sp = _lib.SampleParams()                      # struct_size left 0: a round-1 binding
+    t = C.c_int64(-1)
+    assert lib.mi_step_enqueue(None, None, None, 1, 1, C.byref(sp), C.byref(t)) == -1
+    assert b"mi_sample_params.struct_size" in lib.mi_last_error()
+    rows = (C.c_int32 * 1)(0)
+    assert lib.mi_step_enqueue_rows(h, h, rows, 1, None, 1, C.byref(sp), C.byref(t)) == -1
+    # the header and the ctypes mirror agree on both layouts (compiled probe)
+    import subprocess
+    import tempfile
+
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "mi355_decode.h"\nint main(void){printf("%zu %zu %zu %zu\\n", ' \
+          'sizeof(mi_model_desc), sizeof(mi_sample_params), offsetof(mi_sample_params, row_top_p), ' \
+          'offsetof(mi_sample_params, seed));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "p.c").write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(Path(td) / "p.c"), "-o", str(Path(td) / "p")], check=True)
+        out = subprocess.run([str(Path(td) / "p")], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == [C.sizeof(_lib.ModelDesc), C.sizeof(_lib.SampleParams),
+                                     _lib.SampleParams.row_top_p.offset, _lib.SampleParams.seed.offset]
+
+
+def test_integration_stub_is_the_generated_one():
+    """INTEGRATION.md section B shows the reference-side ctypes stub; its struct block is generated from _lib.py."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_stub", ROOT / "tools" / "gen_integration_stub.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.block() in (ROOT / "INTEGRATION.md").read_text(), "run tools/gen_integration_stub.py --write"

@@ -11,7 +11,9 @@ import pytest
 from mlx_parallm_amd.tiny_model import build_tiny_model
 from oracle import ref_generate
 
-GOLDEN = sorted((Path(__file__).resolve().parent / "golden").glob("*.npz"))
+GOLDEN = sorted(p for p in (Path(__file__).resolve().parent / "golden").glob("*.npz") if not p.stem.startswith("wide_"))
+# production-width cases (make_golden_wide.py): minutes of oracle time each, so the CPU suite only checks the files
+WIDE = sorted((Path(__file__).resolve().parent / "golden").glob("wide_*.npz"))
 
 
 def test_golden_files_present():
@@ -36,3 +38,19 @@ def test_oracle_reproduces_golden(path):
             assert np.allclose(lp, g["logprobs"][s], atol=1e-5)
             top = np.take_along_axis(logits, g["top_ids"][s].astype(np.int64), axis=-1)
             assert np.allclose(top, g["top_vals"][s], atol=1e-5)
+
+
+@pytest.mark.parametrize("path", WIDE, ids=[p.stem for p in WIDE])
+def test_wide_golden_files_are_consistent(path):
+    """tests/golden/wide_*.npz (oracle at the Mistral-7B / Qwen3-14B layer shapes): spec and array shapes agree, greedy
+    tokens are the argmax ids, logprobs are log-softmax values.  The oracle run itself takes minutes per case
+    (make_golden_wide.py); the GPU side is tests/test_gpu_golden_wide.py."""
+    g = np.load(path)
+    spec = json.loads(str(g["spec"]))
+    S, B = spec["steps"], spec["B"]
+    assert g["tokens"].shape == (S, B) and g["logprobs"].shape == (S, B)
+    assert g["top_ids"].shape == (S, B, 8) and g["top_vals"].shape == (S, B, 8) and g["margins"].shape == (S, B)
+    assert np.all(np.diff(g["top_vals"], axis=-1) <= 0) and np.all(g["logprobs"] <= 0)
+    assert np.allclose(g["margins"], g["top_vals"][..., 0] - g["top_vals"][..., 1])
+    if spec["temp"] == 0.0:
+        assert np.array_equal(g["tokens"], g["top_ids"][..., 0])

@@ -30,7 +30,7 @@ from mlx_parallm_amd.engine import Engine, SampleArgs  # noqa: E402
 RMS_NOISE, MAX_NOISE, MIN_COS, MAX_RANK = 0.12, 0.6, 0.995, 3
 
 
-@pytest.fixture(scope="module", params=["mistral-7b-bf16", "mistral-7b-int4"])
+@pytest.fixture(scope="module", params=["mistral-7b-bf16", "mistral-7b-int4", "qwen3-14b-bf16", "qwen3-14b-int4"])
 def big(request):
     family, prec = request.param.rsplit("-", 1)
     quant = 4 if prec == "int4" else 0

@@ -272,11 +272,13 @@ def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
 def test_fused_decode_attention(act, Hq, Hkv, D, qk_norm, variant):
     """mi_op_attention_decode: q/k norm + RoPE + KV append + attention + split combine in one launch,
     MFMA (variant 0, 16-bit caches) and VALU (variant 1) kernels: ragged per-row context lengths up to
-    several 256-key rounds, 1 / 3 / 4 splits; the cache must receive exactly the new K / V row."""
+    eight 256-key rounds, 1 / 3 / 4 / 8 splits; the cache must receive exactly the new K / V row."""
     if act == "float32" and variant == 0:
         pytest.skip("the MFMA kernel is for 16-bit caches; float32 runs the VALU kernel either way")
-    B, cap, max_pos = 4, 720, 768
-    offs = [700, 0, 37, 300]
+    # 1023 / 1024 / 1100: the bench's regime (one full 4 x 256-key pass, then a second, nearly empty round per
+    # workgroup); 2047: eight rounds
+    B, cap, max_pos = 8, 2064, 2112
+    offs = [700, 0, 37, 300, 1023, 1024, 1100, 2047]
     cos, sin, c_ref, s_ref = _rope_setup(D, max_pos, 1e6 if qk_norm else 1e4)
     nqkv = (Hq + 2 * Hkv) * D
     kc = round_to(RNG.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
@@ -304,7 +306,7 @@ def test_fused_decode_attention(act, Hq, Hkv, D, qk_norm, variant):
     s = attn_shape(B, 1, Hq, Hkv, D, act, act, 0, cap)
     qkv_d, off_d = dev(qkv.reshape(B, nqkv), act), dev_i32(offs)
     qn_d, kn_d = dev(qn, act), dev(kn, act)
-    for nsplit in (1, 3, 4):
+    for nsplit in (1, 3, 4, 8):
         kc_d, vc_d = dev(kc, act), dev(vc, act)
         out = torch.zeros((B, Hq * D), dtype=qkv_d.dtype, device="cuda")
         part = torch.zeros((B * Hq * nsplit * (D + 2),), dtype=torch.float32, device="cuda")

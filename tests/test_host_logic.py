@@ -147,6 +147,9 @@ def test_lru_caches(tiny):
     msgs = [{"role": "user", "content": "x"}]
     t1 = utils.apply_chat_template_cached(tok, msgs)
     assert "<|im_start|>user" in t1 and t1.endswith("<|im_start|>assistant\n")
-    lru = utils._LRUCache(max_size=2)
-    lru.set("a", 1); lru.set("b", 2); lru.get("a"); lru.set("c", 3)
-    assert lru.get("b") is None and lru.get("a") == 1 and lru.get("c") == 3
+    assert utils.apply_chat_template_cached(tok, [dict(msgs[0], name="ignored")]) is t1      # role + content decide
+    assert utils.apply_chat_template_cached(tok, msgs, add_generation_prompt=False) != t1
+    memo = utils._BoundedMemo(2)
+    memo.put("a", 1); memo.put("b", 2); memo.peek("a"); memo.put("c", 3)
+    assert memo.peek("b") is None and memo.peek("a") == 1 and memo.fetch("c", lambda: 9) == 3 and len(memo) == 2
+    assert memo.fetch("d", lambda: 4) == 4 and memo.peek("a") is None

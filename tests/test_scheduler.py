@@ -206,3 +206,68 @@ def test_server_routes_in_continuous_mode(tiny, parts):
                 m = (await c.get("/debug/metrics")).json()
                 assert m["decode_tokens_total"] > 0 and m["prompt_tokens_total"] > 0
     asyncio.run(go())
+
+
+def test_borrower_never_gets_the_engine_while_a_device_fed_step_is_pending(tiny, parts):
+    """A borrower (logprobs / echo / perplexity) overwrites the engine's device-resident token feed.  It must only be
+    let in when every enqueued step has been read back -- otherwise the step enqueued ahead with tokens=None would
+    continue from the borrower's tokens (scheduler.py borrow race)."""
+    model, tok = parts
+    eng = model.engine
+    sched = ContinuousScheduler(model, tok, max_slots=2)
+    sched.start()
+    done, ev = {}, threading.Event()
+
+    def sink(seq, delta, reason):
+        if reason is not None:
+            done["a"] = list(seq.generated)
+            ev.set()
+
+    p = tok.encode("a sequence that decodes with the next step always enqueued ahead")
+    sched.submit(p, 48, 0.0, 1.0, sink)
+    borrows, bad = 0, []
+    while not ev.is_set():
+        with sched.borrow_engine():
+            borrows += 1
+            if eng._results or sched._step_pending:
+                bad.append((dict(eng._results), sched._step_pending))
+            eng._last_tokens = np.full((5, 1), 7)          # what a borrower's own steps leave in d_next / last_n
+        time.sleep(0.001)
+    sched.stop()
+    want, _ = _alone(tiny, p, 48, tok.eos_token_id)
+    assert borrows >= 3 and not bad, (borrows, bad[:2])
+    assert done["a"] == want
+    assert any(e[0] == "enqueue_rows" and e[2] == "device-tokens" for e in eng.trace)   # pipelining still happened
+
+
+def test_cancel_releases_the_slot(tiny, parts):
+    """Sequence.cancel() (request timed out / client disconnected): the sequence stops at the next step boundary, its
+    sink sees "cancelled", and the only slot goes to the next request instead of decoding to max_tokens."""
+    model, tok = parts
+    sched = ContinuousScheduler(model, tok, max_slots=1)
+    sched.start()
+    got, ev_first, ev_done = {}, threading.Event(), threading.Event()
+
+    def sink_a(seq, delta, reason):
+        if len(seq.generated) >= 3:
+            ev_first.set()
+        if reason is not None:
+            got["a"] = (len(seq.generated), reason)
+
+    def sink_b(seq, delta, reason):
+        if reason is not None:
+            got["b"] = (list(seq.generated), reason)
+            ev_done.set()
+
+    a = sched.submit(tok.encode("abandoned request"), 1500, 0.0, 1.0, sink_a)
+    pb = tok.encode("the next one")
+    sched.submit(pb, 4, 0.0, 1.0, sink_b)
+    queued = sched.submit(tok.encode("cancelled before admission"), 4, 0.0, 1.0, lambda s, d, r: got.setdefault("q", r))
+    queued.cancel()
+    assert ev_first.wait(timeout=60)
+    a.cancel()
+    assert ev_done.wait(timeout=60)
+    sched.stop()
+    want, reason = _alone(tiny, pb, 4, tok.eos_token_id)
+    assert got["a"][1] == "cancelled" and got["a"][0] < 1500
+    assert got["b"] == (want, reason) and got.get("q") == "cancelled"
