@@ -12,7 +12,12 @@ random-init weights (no network for checkpoints), the prompt of `--context` toke
 holding a full replica (rank 0 generates the weights, RCCL broadcast over xGMI) and its own
 batch shard; no collective inside the timed region except the bracketing barriers ("weak").
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused gate|up SwiGLU
+`python bench.py --gpus N` typed as a plain command (no torchrun environment) launches its own N rank processes
+before anything touches a GPU and relays rank 0's line (mlx_parallm_amd.distributed.self_launch).
+
+Rank 0 prints ONE JSON line.  Besides the headline leg (KV in the model dtype, BatchedKVCache semantics) the same
+workload is timed with float32 KV (PagedKVCache semantics: the numerics `batch_generate` really runs in the reference,
+utils.py:392 + base.py:111-112) and reported under `reference_numerics`.  `roofline` is for the dominant kernel (the fused gate|up SwiGLU
 weight-streaming kernel): algorithmic bytes per launch / its mean launch time from HIP events
 on the engine's stream, measured in a second instrumented pass of the same K steps.
 `cpu_baseline` is the oracle's C restatement (oracle/c) timed on this box's host cores on a
@@ -71,39 +76,57 @@ def tensor_specs(cfg):
         yield "lm_head.weight", (V, H), "mat"
 
 
-def load_synthetic(engine, cfg, seed, quant_bits, rank, world, dist):
-    """Random-init weights N(0, 0.02^2) (norm weights = 1) generated on rank 0's GPU, replicated with
-    RCCL broadcasts, optionally MLX-affine quantised (group 64), handed to the engine."""
+def load_synthetic(engine, cfg, seed, quant_bits, rank, world, dist, stats=None, device=None):
+    """Random-init weights N(0, 0.02^2) (norm weights = 1) generated on rank 0, replicated to the other ranks in a few
+    LARGE flat buckets -- one RCCL broadcast per ~1 GiB bucket (a ring over point-to-point xGMI links is per-link
+    bound, so few large collectives) -- optionally MLX-affine quantised (group 64) and handed
+    to the engine as views into the bucket.  ``engine`` None (dry run): everything except the engine calls.
+    ``stats``: dict that receives broadcast_seconds / broadcast_bytes / broadcast_buckets."""
     import torch
 
+    from mlx_parallm_amd import distributed as D
     from mlx_parallm_amd.quant import quantize
 
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     gen = torch.Generator(device=dev)
-    nbytes = 0
-    for idx, (name, shape, kind) in enumerate(tensor_specs(cfg)):
-        if kind == "norm":
-            t = torch.ones(shape, dtype=torch.bfloat16, device=dev)
-        else:
-            t = torch.empty(shape, dtype=torch.bfloat16, device=dev)
-            if rank == 0:
-                gen.manual_seed(seed * 1000003 + idx)
-                t.copy_(torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) * 0.02)
+    specs = list(tensor_specs(cfg))
+    kinds = {name: kind for name, _shape, kind in specs}
+    index = {name: i for i, (name, _s, _k) in enumerate(specs)}
+    nbytes, bsec, bbytes = 0, 0.0, 0
+    buckets = D.plan_buckets([(n, sh) for n, sh, _k in specs], elem_size=2, bucket_bytes=1 << 30)
+    for bucket in buckets:
+        flat = torch.empty(D.bucket_numel(bucket), dtype=torch.bfloat16, device=dev)
+        views = {name: flat[off:off + n].view(shape) for name, shape, off, n in bucket}
+        if rank == 0:
+            for name, t in views.items():
+                if kinds[name] == "norm":
+                    t.fill_(1.0)
+                else:
+                    gen.manual_seed(seed * 1000003 + index[name])
+                    t.copy_(torch.randn(t.shape, generator=gen, device=dev, dtype=torch.float32) * 0.02)
         if world > 1:
-            dist.broadcast(t, src=0)
-        if kind == "mat" and quant_bits:
-            packed, scales, biases = quantize(t, 64, quant_bits)
-            base = name[: -len(".weight")]
-            engine.set_tensor(base + ".weight", packed)
-            engine.set_tensor(base + ".scales", scales)
-            engine.set_tensor(base + ".biases", biases)
-            nbytes += packed.numel() * 4 + scales.numel() * 4
-        else:
-            engine.set_tensor(name, t)
-            nbytes += t.numel() * 2
-        del t
-    torch.cuda.synchronize()
-    engine.finalize()
+            sec, nb = D.broadcast_bucket(flat, src=0)
+            bsec, bbytes = bsec + sec, bbytes + nb
+        for name, t in views.items():
+            if kinds[name] == "mat" and quant_bits:
+                packed, scales, biases = quantize(t, 64, quant_bits)
+                base = name[: -len(".weight")]
+                if engine is not None:
+                    engine.set_tensor(base + ".weight", packed)
+                    engine.set_tensor(base + ".scales", scales)
+                    engine.set_tensor(base + ".biases", biases)
+                nbytes += packed.numel() * 4 + scales.numel() * 4
+            else:
+                if engine is not None:
+                    engine.set_tensor(name, t)
+                nbytes += t.numel() * 2
+        del views, flat
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    if engine is not None:
+        engine.finalize()
+    if stats is not None:
+        stats.update(broadcast_seconds=round(bsec, 4), broadcast_bytes=int(bbytes), broadcast_buckets=len(buckets) if world > 1 else 0)
     return nbytes
 
 
@@ -118,7 +141,7 @@ def streamed_weight_bytes(cfg, quant_bits):
     return params * bpp, params
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -128,10 +151,12 @@ def main():
                              "qwen3-14b-int8", "tiny-bf16"])
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
     ap.add_argument("--context", type=int, default=1024)
-    ap.add_argument("--kv-dtype", default="model", choices=["model", "float32"])
+    ap.add_argument("--kv-dtype", default="model", choices=["model", "float32"],
+                    help="KV mode of the HEADLINE leg (the other mode is still reported, under reference_numerics / model_kv)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-timing", action="store_true")
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the leg in the other KV mode")
     ap.add_argument("--lora", type=int, default=0, metavar="LAYERS",
                     help="apply rank-16 LoRA adapters (scale 10) to q_proj / v_proj of the last LAYERS blocks "
                          "(BASELINE config 5 uses 8; SURVEY §8d)")
@@ -139,9 +164,76 @@ def main():
     ap.add_argument("--profile-kernel", default="gemv_gate_up")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (A/B experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend; gloo only to rehearse N > 1 on a single-GPU box")
+                    help="process-group backend; gloo only to rehearse N > 1 on a single-GPU box or on CPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the multi-process protocol without an engine (launch, rendezvous, bucketed weight "
+                         "broadcast, barrier / max-over-ranks timing) -- the only mode that runs without a GPU; "
+                         "prints a line with value = null")
+    return ap.parse_args(argv)
+
+
+def decode_leg(engine, cfg, args, kv_dtype, prompts, sample, dist, world, cap):
+    """Prefill (timed separately, after one untimed pass on a cache of its own) + W warm-up steps + EXACTLY K timed
+    steps bracketed by barrier + device sync, MAX over ranks; then K more steps with the dominant kernel's launches
+    bracketed by HIP events on the engine's own stream."""
+    import torch
+
+    B, K, W = args.batch, args.steps, args.warmup
+    kv = engine.new_kv(B, capacity=cap, kv_dtype=kv_dtype)
+    if not args.no_prefill_timing:
+        kv_warm = engine.new_kv(B, capacity=cap, kv_dtype=kv_dtype)
+        engine.step_wait(engine.step_enqueue(kv_warm, prompts, sample), B)
+        kv_warm.close()
+    engine.sync()
+    t0 = time.perf_counter()
+    engine.step_wait(engine.step_enqueue(kv, prompts, sample), B)
+    t_prefill = time.perf_counter() - t0
+
+    def run_steps(n):
+        last = None
+        for _ in range(n):
+            last = engine.step_enqueue(kv, None, sample)               # tokens stay on the device
+        return last
+
+    last = run_steps(W)
+    if last is not None:
+        engine.step_wait(last, B)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    engine.sync()
+    t0 = time.perf_counter()
+    last = run_steps(K)
+    engine.step_wait(last, B)
+    engine.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed, t_prefill], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, t_prefill = float(tt[0].item()), float(tt[1].item())
+    engine.profile_select(args.profile_kernel)
+    last = run_steps(K)
+    engine.step_wait(last, B)
+    n_launch, total_ms = engine.profile_read()
+    engine.profile_select(None)
+    kv.close()
+    return dict(elapsed=elapsed, t_prefill=t_prefill, n_launch=n_launch, total_ms=total_ms)
+
+
+def main():
+    args = parse_args()
+    if os.environ.get("WORLD_SIZE") is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched a GPU yet, and
+        # the ranks are fresh child processes (never an exec of a process that initialised HIP).
+        from mlx_parallm_amd.distributed import self_launch
+
+        sys.exit(self_launch([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus,
+                             local_ranks=[0] * args.gpus if args.same_device else None))
 
     import numpy as np
     import torch
@@ -150,11 +242,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` plainly, or under "
+                         "torch.distributed.run --nproc-per-node N with the same N")
     if args.same_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    have_gpu = torch.cuda.is_available() if not args.dry_run else (args.backend == "nccl" and torch.cuda.is_available())
+    if not args.dry_run and not have_gpu:
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU backend (use --dry-run to rehearse the "
+                         "multi-process protocol on a CPU-only host)")
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -165,8 +262,6 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    from mlx_parallm_amd.engine import Engine, SampleArgs
-
     family, prec = args.workload.rsplit("-", 1)
     quant_bits = {"int4": 4, "int8": 8}.get(prec, 0)
     cfg = dict(SHAPES[family])
@@ -174,12 +269,52 @@ def main():
         cfg["quantization"] = {"group_size": 64, "bits": quant_bits}
     B, ctx, K, W = args.batch, args.context, args.steps, args.warmup
     cap = ctx + 2 * (K + W) + 8
+    bstats = {}
+    ranks_seen = world
+    if world > 1:                                   # every rank reports in: "RCCL ranks seen" of the output line
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+
+    if args.dry_run:
+        t0 = time.perf_counter()
+        wdev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
+        load_synthetic(None, cfg, args.seed, quant_bits, rank, world, dist, stats=bstats, device=wdev)
+        t_load = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (1 + rank))                                     # stands in for the K steps: rank r takes longer
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (args.backend == "nccl") else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        if rank == 0:
+            print(json.dumps({"metric": "decode_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
+                              "steps": K, "warmup": W, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dry_run": True, "data": "synthetic", "ranks_seen": ranks_seen,
+                              "backend": args.backend, "load_seconds": round(t_load, 2),
+                              "rehearsal_barrier_seconds": round(elapsed, 4), **bstats,
+                              "config": {"workload": f"{family} shape ({args.workload}), DRY RUN: no engine, no decode",
+                                         "batch_per_gpu": B, "global_batch": B * world,
+                                         "parallelism": f"dp{world} (batch-sharded replicas, no collective in the decode step)"}}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from mlx_parallm_amd.engine import Engine, SampleArgs
+
     engine = Engine(cfg, device=local_rank, max_positions=max(cap, 2048), act_dtype="bfloat16")
     for kv_ in args.opt:
         k_, v_ = kv_.split("=")
         engine.set_option(k_, int(v_))
     t0 = time.perf_counter()
-    load_synthetic(engine, cfg, args.seed, quant_bits, rank, world, dist)
+    load_synthetic(engine, cfg, args.seed, quant_bits, rank, world, dist, stats=bstats)
     if args.lora:
         # A ~ U(-1/sqrt(K), 1/sqrt(K)), B ~ N(0, 0.01^2), rank 16, scale 10 (lora_init.py:68-72 defaults)
         H, nh, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
@@ -194,126 +329,110 @@ def main():
 
     rng = np.random.default_rng(args.seed + 17 * rank)                 # each rank decodes its own shard
     prompts = rng.integers(0, cfg["vocab_size"], size=(B, ctx)).astype(np.int32)
-    kv = engine.new_kv(B, capacity=cap, kv_dtype=args.kv_dtype)
     # greedy for the bf16 configurations (BASELINE configs 2, 4); top-p 0.9 at temperature 1 with
     # log-probabilities for the int4 configuration (config 3).  `greedy` names the per-step sampler either way.
     greedy = SampleArgs(temp=1.0, top_p=0.9, seed=args.seed) if (quant_bits and not args.greedy) else SampleArgs(temp=0.0)
 
-    # ---- prefill (timed separately: "prefill tok/s"); one untimed pass first, on a cache of its own, so that the
-    # timed pass does not pay the first-launch costs of the prefill kernels (code object load, LDS attributes)
-    if not args.no_prefill_timing:
-        kv_warm = engine.new_kv(B, capacity=cap, kv_dtype=args.kv_dtype)
-        engine.step_wait(engine.step_enqueue(kv_warm, prompts, greedy), B)
-        kv_warm.close()
-    engine.sync()
-    t0 = time.perf_counter()
-    ticket = engine.step_enqueue(kv, prompts, greedy)
-    engine.step_wait(ticket, B)
-    t_prefill = time.perf_counter() - t0
-
-    def run_steps(n):
-        last = None
-        for _ in range(n):
-            last = engine.step_enqueue(kv, None, greedy)               # tokens stay on the device
-        return last
-
-    last = run_steps(W)
-    if last is not None:
-        engine.step_wait(last, B)
-    # ---- timed region: exactly K steps, barrier + device sync on both sides, max over ranks
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    engine.sync()
-    t0 = time.perf_counter()
-    last = run_steps(K)
-    engine.step_wait(last, B)
-    engine.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- dominant kernel: mean launch duration from HIP events on the engine's stream
-    kern = args.profile_kernel
-    engine.profile_select(kern)
-    last = run_steps(K)
-    engine.step_wait(last, B)
-    n_launch, total_ms = engine.profile_read()
-    engine.profile_select(None)
+    head = decode_leg(engine, cfg, args, args.kv_dtype, prompts, greedy, dist, world, cap)
+    other_mode = "float32" if args.kv_dtype == "model" else "model"
+    other = None if args.no_second_leg else decode_leg(engine, cfg, args, other_mode, prompts, greedy, dist, world, cap)
 
     w_bytes, n_params = streamed_weight_bytes(cfg, quant_bits)
     H, I = cfg["hidden_size"], cfg["intermediate_size"]
     nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
     D = cfg.get("head_dim") or H // nh
-    kvb = 2 if args.kv_dtype == "model" else 4
     S_mid = ctx + W + K // 2
-    step_bytes = (w_bytes + B * cfg["num_hidden_layers"] * 2 * nkv * D * S_mid * kvb
-                  + B * cfg["num_hidden_layers"] * 2 * nkv * D * kvb + B * cfg["vocab_size"] * 4)
     bpp = 2.0 if not quant_bits else quant_bits / 8.0 + 4.0 / 64.0
-    kern_bytes = {
-        "gemv_gate_up": 2 * I * H * bpp + B * H * 2 + B * I * 2,
-        "gemv_down": I * H * bpp + B * I * 2 + 2 * B * H * 2,
-        "gemv_qkv": (nh + 2 * nkv) * D * H * bpp + B * H * 2 + B * (nh + 2 * nkv) * D * 2,
-        "gemv_o": H * nh * D * bpp + B * nh * D * 2 + 2 * B * H * 2,
-        "gemv_head": cfg["vocab_size"] * H * bpp + B * H * 2 + B * cfg["vocab_size"] * 4,
-    }.get(kern, 0.0)
+    kern = args.profile_kernel
 
-    def pmc_traffic():
-        """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, own
-        rocprofv3 --pmc runs of this same command): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request
-        on wide coalesced streams, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both reported in KiB."""
-        if args.workload != "mistral-7b-bf16" or kern != "gemv_gate_up" or B != 8:
-            return None
+    def leg_numbers(leg, kv_dtype):
+        kvb = 2 if kv_dtype == "model" else 4
+        ab = 2 if kv_dtype == "model" else 4                    # activation bytes (float32 after layer 0 in PagedKVCache mode)
+        step_bytes = (w_bytes + B * cfg["num_hidden_layers"] * 2 * nkv * D * S_mid * kvb
+                      + B * cfg["num_hidden_layers"] * 2 * nkv * D * kvb + B * cfg["vocab_size"] * 4)
+        kern_bytes = {
+            "gemv_gate_up": 2 * I * H * bpp + B * H * ab + B * I * ab,
+            "gemv_down": I * H * bpp + B * I * ab + 2 * B * H * ab,
+            "gemv_qkv": (nh + 2 * nkv) * D * H * bpp + B * H * ab + B * (nh + 2 * nkv) * D * ab,
+            "gemv_o": H * nh * D * bpp + B * nh * D * ab + 2 * B * H * ab,
+            "gemv_head": cfg["vocab_size"] * H * bpp + B * H * ab + B * cfg["vocab_size"] * 4,
+        }.get(kern, 0.0)
+        ms_per_step = leg["elapsed"] / K * 1e3
+        avg_ms = leg["total_ms"] / max(leg["n_launch"], 1)
+        achieved = kern_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return dict(ms_per_step=ms_per_step, value=world * B * K / leg["elapsed"], step_bytes=step_bytes,
+                    kern_bytes=kern_bytes, avg_ms=avg_ms, achieved=achieved,
+                    prefill=world * B * ctx / leg["t_prefill"])
+
+    def pmc_traffic(kv_dtype):
+        """HBM bytes per launch of the dominant kernel.  NOT measured in this run: read from the committed PMC passes
+        of this same command (profiles/, separate rocprofv3 --pmc runs, as the guide prescribes): 2 x FETCH_SIZE
+        (gfx950 counts 64 B per 128-B request on wide coalesced streams, MI355X_MICROARCH.md HBM section) + WRITE_SIZE,
+        both reported in KiB.  null for any other workload / kernel / batch than the one that was profiled."""
+        if args.workload != "mistral-7b-bf16" or kern != "gemv_gate_up" or B != 8 or kv_dtype != "model":
+            return None, None
         want = "gemv_mfma_kernel<bf16,dense,MB=8,swiglu>"
-        vals = {}
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            f = ROOT / "profiles" / f"round1_pmc_{ctr}.csv"
-            if not f.exists():
-                return None
-            for line in f.read_text().splitlines():
-                if line.startswith(want + ","):
-                    vals[ctr] = float(line.rsplit(",", 1)[1]) * 1024.0
-        if len(vals) != 2:
-            return None
-        return int(2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"])
+        for tag in ("round2", "round1"):
+            vals = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                f = ROOT / "profiles" / f"{tag}_pmc_{ctr}.csv"
+                if not f.exists():
+                    break
+                for line in f.read_text().splitlines():
+                    if line.startswith(want + ","):
+                        vals[ctr] = float(line.rsplit(",", 1)[1]) * 1024.0
+            if len(vals) == 2:
+                return int(2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), \
+                    f"static reference from profiles/{tag}_pmc_{{FETCH,WRITE}}_SIZE.csv (separate rocprofv3 --pmc passes of this command; 2xFETCH_SIZE+WRITE_SIZE), not measured in this run"
+        return None, None
+
+    def roofline_of(num, kv_dtype):
+        traffic, src = pmc_traffic(kv_dtype)
+        return {
+            "bound": "hbm", "kernel": kern, "achieved": round(num["achieved"], 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(num["achieved"] / 8000.0, 4),
+            "frac_of_achievable": round(num["achieved"] / 6290.0, 4),   # of the 6.29 TB/s a streaming kernel reaches (MI355X_MICROARCH.md, HBM)
+            "traffic": traffic, "traffic_source": src,
+            "bytes_per_launch": int(num["kern_bytes"]), "avg_launch_ms": round(num["avg_ms"], 5),
+        }
 
     if rank == 0:
-        ms_per_step = elapsed / K * 1e3
-        value = world * B * K / elapsed
-        avg_ms = total_ms / max(n_launch, 1)
-        achieved = kern_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        hn = leg_numbers(head, args.kv_dtype)
+        kv_names = {"model": "bf16 (BatchedKVCache semantics)", "float32": "float32 (PagedKVCache semantics, the reference's default)"}
         out = {
-            "metric": "decode_tokens_per_sec", "value": round(value, 2), "unit": "tokens/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "metric": "decode_tokens_per_sec", "value": round(hn["value"], 2), "unit": "tokens/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": round(hn["ms_per_step"], 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not quant_bits else f"int{quant_bits}-g64 weights, bf16 activations",
             "data": "synthetic token ids; random-init weights N(0,0.02^2)",
             "config": {
                 "workload": f"{family} shape ({args.workload}), batch {B}/GPU, "
-                            + ("top-p 0.9 / T=1 sampling with logprobs" if quant_bits else "greedy decode") + f" from KV length {ctx}"
+                            + ("top-p 0.9 / T=1 sampling with logprobs" if (quant_bits and not args.greedy) else "greedy decode") + f" from KV length {ctx}"
                             + (f", rank-16 LoRA on q/v of the last {args.lora} layers" if args.lora else ""),
                 "batch_per_gpu": B, "global_batch": B * world, "context": ctx,
-                "kv_dtype": "bf16" if args.kv_dtype == "model" else "float32 (PagedKVCache quirk mode)",
+                "kv_dtype": kv_names[args.kv_dtype],
                 "parallelism": f"dp{world} (batch-sharded replicas, no collective in the decode step)",
             },
-            "roofline": {
-                "bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4),
-                "frac_of_achievable": round(achieved / 6290.0, 4),      # of the 6.29 TB/s a streaming kernel reaches (MI355X_MICROARCH.md, HBM)
-                "traffic": pmc_traffic(),
-                "traffic_source": "profiles/round1_pmc_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes; 2xFETCH_SIZE+WRITE_SIZE)",
-                "bytes_per_launch": int(kern_bytes), "avg_launch_ms": round(avg_ms, 5), "launches": n_launch,
-            },
-            "step_bytes": int(step_bytes),
-            "step_hbm_frac": round(step_bytes / (ms_per_step * 1e-3) / 8e12, 4),
-            "step_hbm_frac_of_achievable": round(step_bytes / (ms_per_step * 1e-3) / 6.29e12, 4),
-            "prefill_tokens_per_sec": round(world * B * ctx / t_prefill, 1),
+            "roofline": dict(roofline_of(hn, args.kv_dtype), launches=head["n_launch"]),
+            "step_bytes": int(hn["step_bytes"]),
+            "step_hbm_frac": round(hn["step_bytes"] / (hn["ms_per_step"] * 1e-3) / 8e12, 4),
+            "step_hbm_frac_of_achievable": round(hn["step_bytes"] / (hn["ms_per_step"] * 1e-3) / 6.29e12, 4),
+            "prefill_tokens_per_sec": round(hn["prefill"], 1),
             "load_seconds": round(t_load, 2),
+            "ranks_seen": ranks_seen,
         }
+        out.update(bstats)
+        if other is not None:
+            on = leg_numbers(other, other_mode)
+            out["reference_numerics" if other_mode == "float32" else "model_kv"] = {
+                "what": f"the same workload and timing protocol with KV {kv_names[other_mode]}"
+                        + ("; ids bit-exact / logprobs <= 1e-3 vs the oracle are asserted in THIS mode (tests/test_gpu_engine.py, test_gpu_golden_wide.py)"
+                           if other_mode == "float32" else ""),
+                "value": round(on["value"], 2), "unit": "tokens/s", "ms_per_step": round(on["ms_per_step"], 4),
+                "prefill_tokens_per_sec": round(on["prefill"], 1),
+                "step_bytes": int(on["step_bytes"]),
+                "step_hbm_frac": round(on["step_bytes"] / (on["ms_per_step"] * 1e-3) / 8e12, 4),
+                "roofline": dict(roofline_of(on, other_mode), launches=other["n_launch"]),
+            }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_ref
 
@@ -327,7 +446,6 @@ def main():
                            f"x{cfg['num_hidden_layers']}/{nl_s}; not MLX (unavailable offline)"),
             }
         print(json.dumps(out), flush=True)
-    kv.close()
     engine.close()
     if world > 1:
         dist.destroy_process_group()

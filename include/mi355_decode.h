@@ -97,6 +97,9 @@ typedef struct mi_sample_params {
                                     * the server's logprobs path reports (server/main.py:571-584) */
   const float* row_temperature;    /* both NULL: `temperature` / `top_p` apply to every row.  Both [B]: per-row */
   const float* row_top_p;          /* values (continuous batching, where requests with different settings share a step) */
+  int64_t stream_position;         /* Philox counter of this step when uniforms == NULL: >= 0 = the caller's own step index
+                                    * (generate_step passes 0, 1, 2, ...: the same seed then reproduces the same tokens,
+                                    * like re-seeding mx.random before a call); < 0 = the engine's running step counter */
 } mi_sample_params;
 
 #define MI_MAX_TOP_LOGPROBS 20

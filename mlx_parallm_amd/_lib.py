@@ -46,6 +46,7 @@ class SampleParams(C.Structure):
         ("uniforms", C.POINTER(C.c_float)), ("seed", C.c_uint64), ("top_logprobs", C.c_int32),
         ("logprobs_at_temperature", C.c_int32),
         ("row_temperature", C.POINTER(C.c_float)), ("row_top_p", C.POINTER(C.c_float)),
+        ("stream_position", C.c_int64),
     ]
 
 

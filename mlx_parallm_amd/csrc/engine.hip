@@ -655,7 +655,7 @@ int check_params(const mi_sample_params* sp) {
 }
 
 int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* forced = nullptr) {
-  mi_sample_params def{}; def.struct_size = sizeof(def); def.temperature = 0.f; def.top_p = 1.f;
+  mi_sample_params def{}; def.struct_size = sizeof(def); def.temperature = 0.f; def.top_p = 1.f; def.stream_position = -1;
   if (!sp) sp = &def;
   hipStream_t st = e->stream;
   if (sp->n_logit_bias > 0) {
@@ -682,7 +682,7 @@ int run_sample(mi_engine* e, int B, const mi_sample_params* sp, const int32_t* f
   sc.temperature = sp->temperature; sc.top_p = sp->top_p;
   sc.n_bias = sp->n_logit_bias; sc.bias_ids = e->d_bias_ids; sc.bias_vals = e->d_bias_vals;
   sc.forced = forced;
-  sc.uniforms = (sp->uniforms && !forced) ? e->d_uniforms : nullptr; sc.seed = sp->seed; sc.step = e->step_counter++;
+  sc.uniforms = (sp->uniforms && !forced) ? e->d_uniforms : nullptr; sc.seed = sp->seed; sc.step = sp->stream_position >= 0 ? (uint64_t)sp->stream_position : e->step_counter++;
   sc.top_logprobs = sp->top_logprobs;
   sc.lp_temp = sp->logprobs_at_temperature;
   sc.row_temp = per_row ? e->d_rowpar : nullptr;

@@ -128,3 +128,157 @@ def sharded_batch_generate(generate_fn: Callable[[List[str]], List[str]], prompt
     if len(local) != len(mine):
         raise RuntimeError("generate_fn must return one response per prompt")
     return gather_in_rank_order(local, dst=dst)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# weight replication without staging copies: every rank carves the SAME flat buckets, the loading rank fills them,
+# one collective per bucket, and the tensors handed to mi_engine_set_tensor are views into the bucket
+def plan_buckets(specs: Iterable[Tuple[str, Tuple[int, ...]]], elem_size: int, bucket_bytes: int = 1 << 30):
+    """specs: (name, shape) in load order -> list of buckets, each a list of (name, shape, offset_elems, numel);
+    a bucket closes when the next tensor would push it past ``bucket_bytes`` (a larger tensor gets a bucket of its own).
+    Offsets are multiples of 128 elements so that every view is 256-byte aligned for 16-bit types."""
+    buckets, cur, off = [], [], 0
+    for name, shape in specs:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if cur and (off + n) * elem_size > bucket_bytes:
+            buckets.append(cur)
+            cur, off = [], 0
+        cur.append((name, tuple(int(d) for d in shape), off, n))
+        off += (n + 127) // 128 * 128
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def bucket_numel(bucket) -> int:
+    name, shape, off, n = bucket[-1]
+    return off + (n + 127) // 128 * 128
+
+
+def broadcast_bucket(flat, src: int = 0) -> Tuple[float, int]:
+    """One collective for one flat bucket (RCCL over xGMI under "nccl").  -> (seconds, bytes); (0, 0) single process."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0.0, 0
+    if flat.is_cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dist.broadcast(flat, src=src)
+    if flat.is_cuda:
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0, flat.numel() * flat.element_size()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def self_launch(argv: Sequence[str], nprocs: int, *, local_ranks: Optional[Sequence[int]] = None,
+                extra_env: Optional[Dict[str, str]] = None) -> int:
+    """Run ``argv`` (a full command line) as ``nprocs`` rank processes of one node and relay rank 0's stdout.
+
+    This is what ``python -m torch.distributed.run --nproc-per-node N`` does for the driver, for the case where the
+    user typed the plain command (``python bench.py --gpus N``).  The CALLER MUST NOT HAVE TOUCHED THE GPU: children are
+    fresh processes started with subprocess (never an exec of a GPU-initialised process), each with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set.  Rank 0's stdout goes to this process's stdout line by line
+    (the JSON line of bench.py), every other stream to stderr.  Returns the largest exit code; if one rank fails the
+    others are terminated (they would otherwise wait at a collective for ever)."""
+    import subprocess
+    import sys
+    import threading
+    import time
+
+    port = free_port()
+    procs = []
+    for r in range(nprocs):
+        env = dict(os.environ)
+        env.update(RANK=str(r), WORLD_SIZE=str(nprocs), LOCAL_RANK=str(local_ranks[r] if local_ranks else r),
+                   LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+
+    def relay(p, rank):
+        for line in p.stdout:
+            if rank == 0:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(f"[rank {rank}] {line}")
+
+    threads = [threading.Thread(target=relay, args=(p, r), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    codes: List[Optional[int]] = [None] * nprocs
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):                # exactly the children started above, by handle
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    return max(abs(int(c)) for c in codes)
+
+
+def replicate_checkpoint(weights: Optional[Dict[str, "object"]], src: int = 0, device=None,
+                         bucket_bytes: int = 1 << 30, stats: Optional[Dict[str, float]] = None) -> Dict[str, "object"]:
+    """Every rank ends up with the checkpoint tensors of rank ``src`` (which read them from disk; the others pass None):
+    the manifest (names, shapes, dtypes) travels as a small object, the bytes as one broadcast per flat bucket and
+    dtype, straight into device memory (``device``: a torch.device; default cuda:<current> when available, else CPU).
+    Returned tensors are views into the buckets -- ``mi_engine_set_tensor`` copies out of them."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(weights or {})
+    rank = dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    manifest = [[(k, tuple(t.shape), str(t.dtype)) for k, t in sorted(weights.items())]] if rank == src else [None]
+    dist.broadcast_object_list(manifest, src=src)
+    by_dtype: Dict[str, List[Tuple[str, Tuple[int, ...]]]] = {}
+    for name, shape, dt in manifest[0]:
+        by_dtype.setdefault(dt, []).append((name, shape))
+    out: Dict[str, "object"] = {}
+    secs, nbytes, nb = 0.0, 0, 0
+    for dt, items in by_dtype.items():
+        tdt = getattr(torch, dt.split(".")[-1])
+        wire = torch.int32 if tdt == torch.uint32 else tdt          # (collectives do not take uint32)
+        esz = torch.empty(0, dtype=wire).element_size()
+        for bucket in plan_buckets(items, esz, bucket_bytes):
+            flat = torch.empty(bucket_numel(bucket), dtype=wire, device=device)
+            if rank == src:
+                for name, shape, off, n in bucket:
+                    flat[off:off + n].copy_(weights[name].reshape(-1).view(wire) if weights[name].dtype != wire
+                                            else weights[name].reshape(-1))
+            s, b = broadcast_bucket(flat, src=src)
+            secs, nbytes, nb = secs + s, nbytes + b, nb + 1
+            for name, shape, off, n in bucket:
+                out[name] = flat[off:off + n].view(shape)
+    if stats is not None:
+        stats.update(broadcast_seconds=round(secs, 4), broadcast_bytes=int(nbytes), broadcast_buckets=nb)
+    return out

@@ -50,7 +50,7 @@ class SampleArgs:
 
     def __init__(self, temp: float = 0.0, top_p: float = 1.0, logit_bias: Optional[Dict[int, float]] = None,
                  uniforms: Optional[Sequence[float]] = None, seed: int = 0, top_logprobs: int = 0,
-                 logprobs_at_temperature: bool = False):
+                 logprobs_at_temperature: bool = False, stream_position: int = -1):
         self.c = L.SampleParams()
         self.c.struct_size = C.sizeof(L.SampleParams)
         self.c.temperature = float(temp)
@@ -58,6 +58,7 @@ class SampleArgs:
         self.c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.c.top_logprobs = int(top_logprobs)
         self.c.logprobs_at_temperature = 1 if logprobs_at_temperature else 0
+        self.c.stream_position = int(stream_position)      # >= 0: Philox counter = the caller's step index (reproducible)
         self._keep = []
         if logit_bias:
             ids = np.ascontiguousarray(list(logit_bias.keys()), dtype=np.int32)

@@ -203,7 +203,8 @@ def generate_step(
     ``softmax(logits)[0, tokens]`` as in the reference (utils.py:363).  Like the reference
     (utils.py:420-427) step n+1 is launched before step n's tokens are read back.
 
-    Extensions (keyword only): ``seed`` (Philox key for temp > 0), ``uniforms_fn(step) -> (B,)``
+    Extensions (keyword only): ``seed`` (Philox key for temp > 0; the counter is the step index of THIS generation,
+    so the same seed reproduces the same tokens), ``uniforms_fn(step) -> (B,)``
     caller-supplied noise, ``top_logprobs``, ``return_details`` (yield the dict ``tokens / logprobs /
     probs_row0 / top_ids / top_logprobs`` instead), ``logprobs_at_temperature`` (report logprobs under
     ``softmax(logits / temp)``, as the server's logprobs path does, instead of ``softmax(logits)``).
@@ -224,7 +225,8 @@ def generate_step(
     def args_for(step: int) -> SampleArgs:
         u = uniforms_fn(step) if (uniforms_fn is not None and temp != 0) else None
         return SampleArgs(temp=temp, top_p=top_p, logit_bias=logit_bias, uniforms=u, seed=seed,
-                          top_logprobs=top_logprobs, logprobs_at_temperature=logprobs_at_temperature)
+                          top_logprobs=top_logprobs, logprobs_at_temperature=logprobs_at_temperature,
+                          stream_position=step)
 
     def emit(res):
         if return_details:
@@ -364,23 +366,42 @@ def _checkpoint_dtype(weights: Dict[str, Any]) -> str:
 
 
 def load_model(model_path: Path, lazy: bool = False, model_config: dict = {}, *, device: int = 0,
-               max_positions: Optional[int] = None):
+               max_positions: Optional[int] = None, weights_from_rank: Optional[int] = None,
+               replicate_stats: Optional[Dict[str, float]] = None):
     """utils.py:630-708: config.json -> glob ``model*.safetensors`` -> Model(args) -> sanitize ->
-    quantised modules are those with a ``.scales`` tensor -> unknown tensors filtered."""
+    quantised modules are those with a ``.scales`` tensor -> unknown tensors filtered.
+
+    ``weights_from_rank`` (keyword only; needs an initialised ``torch.distributed`` group): only that rank reads the
+    safetensors files, the other ranks receive the tensors by bucketed broadcast straight into device memory
+    (``distributed.replicate_checkpoint``: RCCL over xGMI under backend "nccl") -- SURVEY 8e."""
     from safetensors.torch import load_file
 
     model_path = Path(model_path)
     config = load_config(model_path)
     config.update(model_config)
-    weight_files = glob.glob(str(model_path / "model*.safetensors"))
-    if not weight_files:
-        weight_files = glob.glob(str(model_path / "weight*.safetensors"))       # back-compat, utils.py:659-661
-    if not weight_files:
-        logging.error(f"No safetensors found in {model_path}")
-        raise FileNotFoundError(f"No safetensors found in {model_path}")
+    reader = True
+    if weights_from_rank is not None:
+        import torch.distributed as dist
+
+        reader = (not dist.is_initialized()) or dist.get_rank() == weights_from_rank
     weights: Dict[str, Any] = {}
-    for wf in sorted(weight_files):
-        weights.update(load_file(wf))
+    if reader:
+        weight_files = glob.glob(str(model_path / "model*.safetensors"))
+        if not weight_files:
+            weight_files = glob.glob(str(model_path / "weight*.safetensors"))   # back-compat, utils.py:659-661
+        if not weight_files:
+            logging.error(f"No safetensors found in {model_path}")
+            raise FileNotFoundError(f"No safetensors found in {model_path}")
+        for wf in sorted(weight_files):
+            weights.update(load_file(wf))
+    if weights_from_rank is not None:
+        import torch
+
+        from .distributed import replicate_checkpoint
+
+        dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
+        weights = replicate_checkpoint(weights if reader else None, src=weights_from_rank, device=dev,
+                                       stats=replicate_stats)
     model_class, model_args_class = _get_classes(config=config)
     model_args = model_args_class.from_dict(config)
     dtype = _checkpoint_dtype(weights)

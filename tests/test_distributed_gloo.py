@@ -68,3 +68,68 @@ def test_two_process_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _replicate_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_distributed(backend="gloo")
+    g = torch.Generator().manual_seed(3)
+    ckpt = {"a.weight": torch.randn((33, 7), generator=g).to(torch.bfloat16),
+            "b.weight": torch.randint(-2 ** 31, 2 ** 31 - 1, (5, 9), generator=g, dtype=torch.int64).to(torch.int32).view(torch.uint32),
+            "b.scales": torch.randn((5, 3), generator=g).to(torch.bfloat16),
+            "n.weight": torch.randn((11,), generator=g)}
+    stats = {}
+    got = D.replicate_checkpoint(ckpt if rank == 0 else None, src=0, device=torch.device("cpu"), bucket_bytes=256,
+                                 stats=stats)
+    assert sorted(got) == sorted(ckpt)
+    for k, t in ckpt.items():
+        want = t.view(torch.int32) if t.dtype == torch.uint32 else t
+        assert got[k].shape == t.shape and torch.equal(got[k], want), k
+    assert stats["broadcast_buckets"] >= 3 and stats["broadcast_bytes"] >= sum(t.numel() * t.element_size() for t in ckpt.values())
+    open(os.path.join(out_dir, f"rep{rank}"), "w").write("ok")
+    torch.distributed.destroy_process_group()
+
+
+def test_checkpoint_replication_over_gloo(tmp_path):
+    """utils.load_model(weights_from_rank=0): the reading rank's tensors arrive on every rank by bucketed broadcast."""
+    mp.spawn(_replicate_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"rep{r}").exists() for r in range(2))
+
+
+def test_plan_buckets():
+    specs = [("a", (1000,)), ("b", (10, 100)), ("big", (5000,)), ("c", (3,))]
+    buckets = D.plan_buckets(specs, elem_size=2, bucket_bytes=4096)
+    assert [[e[0] for e in b] for b in buckets] == [["a", "b"], ["big"], ["c"]]       # an oversized tensor gets its own
+    for b in buckets:
+        assert all(off % 128 == 0 for _, _, off, _ in b)
+        assert D.bucket_numel(b) >= b[-1][2] + b[-1][3]
+
+
+def test_bench_self_launches_two_ranks_as_a_plain_command():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts the two ranks itself (before any GPU
+    call), they rendezvous over gloo on 127.0.0.1, replicate the synthetic weights in buckets, run the barrier /
+    max-over-ranks protocol, and rank 0's single JSON line comes back through the parent.  --dry-run: no engine (this
+    host has no GPU); the same path with the engine is tests/test_gpu_bench_contract.py."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny-bf16",
+                          "--steps", "3", "--warmup", "1", "--dry-run"], cwd=str(root), env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["dry_run"] is True and j["value"] is None
+    tiny = 151936 * 64 + 8 * (4 * 64 * 64 + 3 * 128 * 64 + 2 * 64) + 64              # tied embedding: no lm_head
+    assert j["broadcast_buckets"] == 1 and j["broadcast_bytes"] >= 2 * tiny
+    assert j["rehearsal_barrier_seconds"] >= 0.02                                     # the slower rank (rank 1) sets the time
+    # a failing rank takes the launch down instead of leaving the others at a collective
+    bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny-bf16"],
+                         cwd=str(root), env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "needs an MI355X" in bad.stderr

@@ -30,3 +30,55 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["launches"] > 0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "tokens/s" and c["sample"]
+
+
+def test_bench_gpus_2_as_a_plain_command_runs_two_ranks_with_engines():
+    """`python bench.py --gpus 2` (no torchrun): self-launch, rendezvous, bucketed weight broadcast, two engines decoding
+    their own shards, barrier + max-over-ranks timing, one JSON line.  On this one-GPU box the ranks share cuda:0 and
+    talk over gloo (--same-device --backend gloo); on a multi-GPU node the same command uses RCCL."""
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                          "--workload", "tiny-bf16", "--steps", "6", "--warmup", "2", "--context", "64", "--batch", "2",
+                          "--no-cpu-baseline"], cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"
+    assert j["broadcast_buckets"] >= 1 and j["broadcast_bytes"] > 0 and j["broadcast_seconds"] > 0
+    assert j["value"] > 0 and abs(j["value"] - 2 * 2 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 0.01
+    assert "reference_numerics" in j and j["reference_numerics"]["value"] > 0
+    assert "float32" in j["reference_numerics"]["what"]
+
+
+def test_dp_generate_two_ranks_equal_one_process(tiny_dirs, tmp_path):
+    """mlx_parallm_amd.dp_generate: prompts sharded over two ranks (weights replicated from rank 0 by bucketed
+    broadcast) give the responses of the single-process batch_generate on each shard, in prompt order."""
+    from mlx_parallm_amd import utils
+    from mlx_parallm_amd.distributed import shard_range
+
+    d = tiny_dirs["llama_q4_f32"][0]
+    prompts = ["first", "second prompt", "a third, longer prompt", "4th", "and the fifth one"]
+    pf = tmp_path / "prompts.json"
+    pf.write_text(json.dumps(prompts))
+    res = subprocess.run([sys.executable, "-m", "mlx_parallm_amd.dp_generate", "--model-path", d, "--prompts-file", str(pf),
+                          "--gpus", "2", "--backend", "gloo", "--same-device", "--max-tokens", "8", "--kv-dtype", "float32"],
+                         cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    j = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["n_prompts"] == 5 and j["broadcast_bytes"] > 0
+    utils._kv_pool.clear()
+    import pytest as _pt
+
+    mp = _pt.MonkeyPatch()
+    mp.setattr(utils, "DEFAULT_KV_DTYPE", "float32")
+    try:
+        model, tok = utils.load(d)
+        want = []
+        for r in range(2):
+            s, e = shard_range(len(prompts), r, 2)
+            want += utils.batch_generate(model, tok, prompts[s:e], max_tokens=8, temp=0.0)
+        model.engine.close()
+    finally:
+        mp.undo()
+        utils._kv_pool.clear()
+    assert j["responses"] == want

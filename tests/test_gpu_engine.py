@@ -19,6 +19,7 @@ from mlx_parallm_amd import utils  # noqa: E402
 from mlx_parallm_amd.engine import SampleArgs  # noqa: E402
 
 RNG = np.random.default_rng(7)
+MODEL_KV_LOGPROB_TOL = 0.1      # BatchedKVCache (16-bit KV / activations) mode; the float32-KV mode holds 1e-3
 
 # name -> (kv dtype for the product, oracle paged flag, logit atol, logprob atol)
 MODES = {
@@ -131,6 +132,10 @@ def test_greedy_model_dtype_kv_16bit_models(tiny_dirs, name):
     near, total, lp_err = _teacher_forced_greedy(model, ref, cfg, "model", False, B=4, L0=12, steps=20,
                                                  margin_eps=0.13)
     assert near <= max(2, total // 10), (near, total)
+    # chosen-token logprobs on the steps where the ids agree: 16-bit logits carry ~3 ulps of rounding noise each
+    # (|logit| up to ~8 -> ulp 0.03-0.06), the log-sum-exp averages it: measured <= 0.05 on these models
+    print(f"{name}: model-dtype KV max |logprob - oracle| = {lp_err:.4f}")
+    assert lp_err <= MODEL_KV_LOGPROB_TOL, lp_err
     model.engine.close()
 
 
