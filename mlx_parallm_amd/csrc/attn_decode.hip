@@ -391,20 +391,41 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
-template <int G, int D>
+template <int G, int D, int ES = 2>
+__host__ __device__ constexpr size_t attn_mfma_vimg_bytes() { return ES == 2 ? (size_t)8 * 32 * D * 2 : 0; }   // float32 caches: no V image
+
+template <int G, int D, int ES = 2>
 __host__ __device__ constexpr size_t attn_mfma_lds_bytes() {
-  // [V images: 8 waves x 32 keys x D x 2 B][q + new key: (G + 1) x D x 2 B][st_o: 9 x G x D floats][st_m, st_l: 9 x G floats each]
-  return (size_t)8 * 32 * D * 2 + (size_t)(G + 1) * D * 2 + (size_t)9 * G * D * 4 + (size_t)2 * 9 * G * 4 + 16;
+  // [V images: 8 waves x 32 keys x D x 2 B (16-bit caches only)][q + new key: (G + 1) x D x ES B][st_o: 9 x G x D floats]
+  // [st_m, st_l: 9 x G floats each]
+  return attn_mfma_vimg_bytes<G, D, ES>() + (size_t)(G + 1) * D * ES + (size_t)9 * G * D * 4 + (size_t)2 * 9 * G * 4 + 16;
 }
+
+// float32 caches (the PagedKVCache mode, base.py:104-140): v_mfma_f32_16x16x4_f32 -- exact float32 products, one float per
+// lane and operand.  The MFMA k index and the row index of the A operand are free labellings, which lets every operand
+// come straight from 16-byte global loads with no LDS image and no transpose:
+//   * S^T = K Q^T: lane (c16 = key, g4) loads K[key][16 i + 4 g4 .. + 3] (i < D/16: per instruction a row gives 64
+//     contiguous bytes, as in the 16-bit kernel); step (i, e) multiplies element e of piece i, i.e. lane group g4
+//     supplies d = 16 i + 4 g4 + e, and lane (c16 = head, g4) holds the same d of q.  Scores land as in the 16-bit
+//     kernel: lane (head, g4) has keys 4 g4 + r.
+//   * O^T = V^T P: step r of a 16-key tile takes key 4 g4 + r from lane group g4 -- exactly the P value that lane holds
+//     in register r.  Lane (c16, g4) loads V[key 4 g4 + r][64 h + 4 c16 .. + 3]: per instruction 256 contiguous bytes of
+//     each of 4 rows; element e of that load is row c16 of the A tile (h, e), so output tile (h, e) row c16' = 4 g4 + reg
+//     is d = 64 h + 4 c16' + e.  D/4 MFMAs per key tile for each product (32 + 32 at D = 128, 32 cycles each).
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 template <typename T>
 __device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
-  if (write_through)   // read by other workgroups of this same launch (attn_decode_o_kernel)
-    __hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
+  if (write_through) {   // read by other workgroups of this same launch (attn_decode_o_kernel)
+    if constexpr (sizeof(T) == 2)
+      __hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      __hip_atomic_store((unsigned*)p, __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
     *p = v;
+  }
 }
 
 // The launch as a device function: `after_loads()` runs once the body's own first global loads are in flight;
@@ -416,9 +437,12 @@ __device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
 // of weight loads per CU sit in front of every dependent load of the attention's latency chain.  Dropped.
 template <typename T, int D, int G, bool NORM, bool WT, class Hook>
 __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, unsigned char* smem, Hook after_loads) {
-  static_assert(sizeof(T) == 2 && D % 32 == 0 && D <= 128 && G <= 8, "16-bit caches, head_dim 32/64/96/128");
-  constexpr int EPL = D / 16, NWV = 8, NW32 = EPL / 2;
+  constexpr bool F32 = sizeof(T) == 4;
+  static_assert(D % 32 == 0 && D <= 128 && G <= 8 && (!F32 || D % 64 == 0), "16-bit caches: head_dim 32/64/96/128; float32: 64/128");
+  constexpr int EPL = D / 16, NWV = 8, NW32 = EPL * (int)sizeof(T) / 4;
   constexpr int KK = D / 32, DT = D / 16, NV = (32 * D * 2) / (64 * 16);   // K steps, 16-d tiles, 16-B V loads per lane
+  constexpr int KPW = F32 ? 16 : 32;             // keys per wave and round
+  constexpr int NP = D / 16, NH = D / 64 > 0 ? D / 64 : 1;   // float32: 16-byte K pieces per lane and tile, 64-d halves of a V row
   constexpr float LOG2E = 1.4426950408889634f;
   const AttnShape& s = c.s;
   const int split = blockIdx.x, bh = blockIdx.y;
@@ -438,9 +462,10 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   const int nq = s.Hq * D;
   const T* row = (const T*)c.qkv + (size_t)b * (nq + 2 * s.Hkv * D);
 
-  unsigned char* vimg = smem + (size_t)wave * (32 * D * 2);          // this wave's V image
-  T* q_sh = (T*)(smem + (size_t)8 * 32 * D * 2);                      // [G + 1][D]: q heads, then the new key
-  float* st_o = (float*)(smem + (size_t)8 * 32 * D * 2 + (size_t)(G + 1) * D * 2);   // [9][G][D]
+  constexpr size_t VIMG = attn_mfma_vimg_bytes<G, D, (int)sizeof(T)>();
+  unsigned char* vimg = smem + (size_t)wave * (32 * D * 2);          // this wave's V image (16-bit caches)
+  T* q_sh = (T*)(smem + VIMG);                                        // [G + 1][D]: q heads, then the new key
+  float* st_o = (float*)(smem + VIMG + (size_t)(G + 1) * D * sizeof(T));   // [9][G][D]
   float* st_m = st_o + 9 * G * D;                                     // [9][G]
   float* st_l = st_m + 9 * G;
   int& is_last_sh = *(int*)(st_l + 9 * G);       // (no static __shared__ in front of the dynamic region)
@@ -450,24 +475,40 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   const int send = min(s0 + chunk, pos);         // cached keys of this split: [s0, send)
 
   // ---- the K fragments and V rows of the first round go out before anything else
-  u32x4 kf[2][KK], vrow[NV];
+  u32x4 kf[F32 ? 1 : 2][F32 ? 1 : KK], vrow[F32 ? 1 : NV];
+  f32x4 kf32[F32 ? NP : 1], vv32[F32 ? 4 : 1][F32 ? NH : 1];
   const int klast = max(send - 1, 0);            // every address is clamped to a valid row: no load sits under a branch
-  auto issue_k = [&](int base) {                 // keys base + 32 wave + [0, 32)
-    const int k0 = base + 32 * wave;
+  auto issue_k = [&](int base) {                 // keys base + KPW wave + [0, KPW)
+    const int k0 = base + KPW * wave;
+    if constexpr (F32) {
+      const int key = min(k0 + c16, klast);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int key = min(k0 + 16 * t + c16, klast);
+      for (int i = 0; i < NP; ++i) kf32[i] = *(const f32x4*)(kc + (size_t)key * D + 16 * i + 4 * g4);
+    } else {
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) kf[t][kk] = *(const u32x4*)(kc + (size_t)key * D + 32 * kk + 8 * g4);
+      for (int t = 0; t < 2; ++t) {
+        const int key = min(k0 + 16 * t + c16, klast);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[t][kk] = *(const u32x4*)(kc + (size_t)key * D + 32 * kk + 8 * g4);
+      }
     }
   };
-  auto issue_v = [&](int base) {                 // 32 keys x (D/8) 16-byte pieces, lane-linear: piece = i * 64 + lane
-    const int k0 = base + 32 * wave;
+  auto issue_v = [&](int base) {
+    const int k0 = base + KPW * wave;
+    if constexpr (F32) {                         // key 4 g4 + r of the tile, 256 contiguous bytes per row and instruction
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int piece = i * 64 + lane, kl = piece / (D / 8), dc = piece % (D / 8);
-      const int key = min(k0 + kl, klast);
-      vrow[i] = *(const u32x4*)(vc + (size_t)key * D + 8 * dc);
+      for (int r = 0; r < 4; ++r) {
+        const int key = min(k0 + 4 * g4 + r, klast);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) vv32[r][h] = *(const f32x4*)(vc + (size_t)key * D + 64 * h + 4 * c16);
+      }
+    } else {                                     // 32 keys x (D/8) 16-byte pieces, lane-linear: piece = i * 64 + lane
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int piece = i * 64 + lane, kl = piece / (D / 8), dc = piece % (D / 8);
+        const int key = min(k0 + kl, klast);
+        vrow[i] = *(const u32x4*)(vc + (size_t)key * D + 8 * dc);
+      }
     }
   };
   issue_k(s0);
@@ -517,8 +558,13 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     x[e] = to_f32(store_act<T>(o, s.rnd));
   }
   uint32_t pk[NW32];
+  if constexpr (F32) {
 #pragma unroll
-  for (int e = 0; e < EPL / 2; ++e) pk[e] = is_v ? raw[e] : pack2<T>(x[2 * e], x[2 * e + 1]);   // v: untouched bits
+    for (int e = 0; e < EPL; ++e) pk[e] = is_v ? raw[e] : __float_as_uint(x[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPL / 2; ++e) pk[e] = is_v ? raw[e] : pack2<T>(x[2 * e], x[2 * e + 1]);   // v: untouched bits
+  }
   if (is_q || is_k) {                            // q heads at rows 0..G-1 of q_sh, the new key at row G
 #pragma unroll
     for (int i = 0; i < NW32; ++i) ((uint32_t*)(q_sh + (size_t)vi * D + li * EPL))[i] = pk[i];
@@ -546,17 +592,32 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     for (int j = 0; j < (G + 3) / 4; ++j) {
       const int g = min(gq + 4 * j, G - 1);
       float d = 0.f;
+      if constexpr (F32) {
 #pragma unroll
-      for (int i = 0; i < NW32; ++i) d = dot2<T>(kn[i], ((const uint32_t*)(q_sh + (size_t)g * D + li * EPL))[i], d);
+        for (int i = 0; i < NW32; ++i)
+          d = fmaf(__uint_as_float(kn[i]), __uint_as_float(((const uint32_t*)(q_sh + (size_t)g * D + li * EPL))[i]), d);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NW32; ++i) d = dot2<T>(kn[i], ((const uint32_t*)(q_sh + (size_t)g * D + li * EPL))[i], d);
+      }
       d = row16_sum(d) * sc2;
       if (li == 0 && gq + 4 * j < G) { st_m[8 * G + g] = owner ? d : -1e30f; st_l[8 * G + g] = owner ? 1.f : 0.f; }
     }
   }
-  u32x4 qf[KK];
+  u32x4 qf[F32 ? 1 : KK];
+  f32x4 qf32[F32 ? NP : 1];
+  if constexpr (F32) {
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) {
-    qf[kk] = *(const u32x4*)(q_sh + (size_t)(c16 < G ? c16 : 0) * D + 32 * kk + 8 * g4);
-    if (c16 >= G) qf[kk] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < NP; ++i) {
+      qf32[i] = *(const f32x4*)(q_sh + (size_t)(c16 < G ? c16 : 0) * D + 16 * i + 4 * g4);
+      if (c16 >= G) qf32[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      qf[kk] = *(const u32x4*)(q_sh + (size_t)(c16 < G ? c16 : 0) * D + 32 * kk + 8 * g4);
+      if (c16 >= G) qf[kk] = u32x4{0u, 0u, 0u, 0u};
+    }
   }
 
   // ---- rounds of 256 keys per workgroup
@@ -564,6 +625,46 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   f32x4 accO[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) accO[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (F32) {
+    for (int base = s0; base < send; base += KPW * NWV) {       // uniform trip count; 16 keys per wave and round
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc = mfma_f32(kf32[i][e], qf32[i][e], sc);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_k(base + KPW * NWV);                 // rolling prefetch: the next round's K into the registers just consumed
+      __builtin_amdgcn_sched_barrier(0);
+      const int k0 = base + KPW * wave;
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (k0 + 4 * g4 + r) < send;
+        sc[r] = ok ? sc[r] * sc2 : -INFINITY;
+        mx = fmaxf(mx, sc[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));    // max over the wave's 16 keys, per head
+      const float mn = fmaxf(m_run, mx);
+      const float corr = __builtin_amdgcn_exp2f(m_run - mn);
+      m_run = mn;
+      l_run *= corr;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) accO[dt] *= corr;
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); l_run += p[r]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accO[h * 4 + e] = mfma_f32(vv32[r][h][e], p[r], accO[h * 4 + e]);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_v(base + KPW * NWV);                 // ... and the next round's V rows
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   for (int base = s0; base < send; base += 32 * NWV) {        // uniform trip count
     // S^T tiles: rows = keys, columns = heads
     f32x4 sc[2];
@@ -622,15 +723,23 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
       accO[dt] = mfma_kq<T>(vf, pf, accO[dt]);
     }
   }
+  }
   // ---- this wave's (m, l, O) for the heads in columns c16 < G
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
   if (c16 < G) {
     if (g4 == 0) { st_m[wave * G + c16] = m_run; st_l[wave * G + c16] = l_run; }
+    if constexpr (F32) {                         // tile (h, e), row 4 g4 + r  <->  d = 64 h + 4 (4 g4 + r) + e
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st_o[(wave * G + c16) * D + 16 * dt + 4 * g4 + r] = accO[dt][r];
+        for (int r = 0; r < 4; ++r) st_o[(wave * G + c16) * D + 64 * (dt >> 2) + 16 * g4 + 4 * r + (dt & 3)] = accO[dt][r];
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_o[(wave * G + c16) * D + 16 * dt + 4 * g4 + r] = accO[dt][r];
+    }
   }
   __syncthreads();
   T* out = (T*)c.out + (size_t)b * nq;
@@ -698,16 +807,19 @@ int launch_mfma_g(const AttnDecodeCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
   auto kern = attn_decode_mfma_kernel<T, D, G, NORM>;
-  constexpr size_t lds = attn_mfma_lds_bytes<G, D>();
+  constexpr size_t lds = attn_mfma_lds_bytes<G, D, (int)sizeof(T)>();
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, grid, block, lds, st, c);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
 
+template <typename T, int D>
+constexpr bool attn_mfma_ok() { return (sizeof(T) == 2 && D % 32 == 0) || (sizeof(T) == 4 && D % 64 == 0); }
+
 template <typename T, int D, bool NORM>
 int launch_mfma_gn(const AttnDecodeCall& c, hipStream_t st) {
-  if constexpr (sizeof(T) == 2 && D % 32 == 0) {
+  if constexpr (attn_mfma_ok<T, D>()) {
     switch (c.s.Hq / c.s.Hkv) {
       case 1: return launch_mfma_g<T, D, 1, NORM>(c, st);
       case 2: return launch_mfma_g<T, D, 2, NORM>(c, st);
@@ -722,7 +834,7 @@ int launch_mfma_gn(const AttnDecodeCall& c, hipStream_t st) {
 template <typename T, int D, bool NORM>
 int launch_gn(const AttnDecodeCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
-  if constexpr (sizeof(T) == 2 && D % 32 == 0) {
+  if constexpr (attn_mfma_ok<T, D>()) {
     if (c.variant != 1) return launch_mfma_gn<T, D, NORM>(c, st);
   }
   const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);

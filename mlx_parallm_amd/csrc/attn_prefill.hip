@@ -210,19 +210,179 @@ int launch_pt(const AttnCall& c, hipStream_t st) {
   return fail(MI_ERR_UNSUPPORTED, "attention_prefill: head_dim must be 32, 64 or 128");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// float32 activations and caches (the PagedKVCache mode: base.py:104-140 keeps float32 K / V, and SDPA then runs in
+// float32 for every layer): the same workgroup shape on v_mfma_f32_16x16x4_f32 -- exact float32 products, one float per
+// lane and operand.  Blocks of 16 keys; both images are laid out in the order the fragments are read, so every LDS
+// read is a lane-linear KiB (conflict-free ds_read_b128):
+//   * K image [i][g4][key] x 16 B: lane (c16 = key, g4) reads K[key][16 i + 4 g4 .. + 3]; MFMA step (i, e) takes element
+//     e, i.e. lane group g4 supplies d = 16 i + 4 g4 + e, and the Q^T fragment holds the same d of the lane's query;
+//   * V image [r][h][g4][c16] x 16 B: lane (c16, g4) reads V[key 4 g4 + r][64 h + 4 c16 .. + 3]; step r of the block takes
+//     key 4 g4 + r from lane group g4 -- the P value that lane already holds in register r -- and element e is row c16 of
+//     the A tile (h, e): output tile (h, e), row 4 g4' + reg, is d = 64 h + 16 g4' + 4 reg + e (attn_decode.hip has the
+//     same labelling for the decode step).
+constexpr int KB32 = 16;    // keys per block, float32 kernel
+
+template <int D, int G>
+__global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
+  static_assert(D % 64 == 0 && D <= 128, "float32: head_dim 64 / 128");
+  constexpr int NP = D / 16, NH = D / 64, DT = D / 16, NT = G * 64;
+  constexpr int NPIECE = KB32 * D / 4;                // 16-byte pieces of one K (or V) block
+  constexpr int NLD = (NPIECE + NT - 1) / NT;         // per thread
+  constexpr int IMG = KB32 * D * 4;                   // bytes of one image
+  constexpr float LOG2E = 1.4426950408889634f;
+  const AttnShape& s = c.s;
+  const int qt = gridDim.x - 1 - blockIdx.x, bh = blockIdx.y;
+  const int b = bh / s.Hkv, kh = bh % s.Hkv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = s.rows ? s.rows[b] : b;              // cache row of batch entry b
+  const int off = c.offsets[kb];
+  const int t0 = qt * QT;
+  const int tq = min(t0 + c16, s.L - 1);              // this lane's query (clamped; stores are guarded)
+  const int nk = off + min(t0 + QT, s.L);             // keys any query of the tile may see
+  const int nb = (nk + KB32 - 1) / KB32;
+  const int h = kh * G + wave;
+
+  __shared__ __attribute__((aligned(16))) unsigned char kimg[2][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char vimg[2][IMG];
+
+  const float* kc = (const float*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  const float* vc = (const float*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+
+  f32x4 kreg[NLD], vreg[NLD];
+  auto load_block = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int piece = min(i * NT + tid, NPIECE - 1);
+      const int key = min(j * KB32 + piece / (D / 4), nk - 1), dc = piece % (D / 4);
+      kreg[i] = *(const f32x4*)(kc + (size_t)key * D + 4 * dc);
+      vreg[i] = *(const f32x4*)(vc + (size_t)key * D + 4 * dc);
+    }
+  };
+  auto store_block = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int piece = i * NT + tid;
+      if (piece < NPIECE) {
+        const int key = piece / (D / 4), dc = piece % (D / 4);     // dc: 16-byte piece of the row, d = 4 dc
+        *(f32x4*)(kimg[buf] + (size_t)(dc * 16 + key) * 16) = kreg[i];                                   // (i, g4) = (dc / 4, dc % 4)
+        *(f32x4*)(vimg[buf] + (size_t)((((key & 3) * NH + (dc >> 4)) * 4 + (key >> 2)) * 16 + (dc & 15)) * 16) = vreg[i];
+      }
+    }
+  };
+
+  load_block(0);
+  f32x4 qf[NP];                                       // Q^T fragments of this wave's head (B operand: column = query)
+  {
+    const float* qp = (const float*)c.q + ((size_t)b * s.L + tq) * s.Hq * D + (size_t)h * D;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) qf[i] = *(const f32x4*)(qp + 16 * i + 4 * g4);
+  }
+  store_block(0);
+  __syncthreads();
+
+  const float sc2 = c.scale * LOG2E;
+  const int qpos = off + t0 + c16;                    // key positions <= qpos are visible to this lane's query
+  float m_run = -1e30f, l_run = 0.f;
+  f32x4 accO[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) accO[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < nb; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < nb) load_block(j + 1);                // uniform branch; the loads fly during this block's MFMAs
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const f32x4 kf = *(const f32x4*)(kimg[buf] + (size_t)((i * 4 + g4) * 16 + c16) * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[i][e], sc, 0, 0, 0);
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (j * KB32 + 4 * g4 + r) <= qpos;
+      sc[r] = ok ? sc[r] * sc2 : -INFINITY;
+      mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m_run, mx);
+    const float corr = __builtin_amdgcn_exp2f(m_run - mn);
+    m_run = mn;
+    l_run *= corr;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) accO[dt] *= corr;
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); l_run += p[r]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        const f32x4 vf = *(const f32x4*)(vimg[buf] + (size_t)(((r * NH + hh) * 4 + g4) * 16 + c16) * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accO[hh * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], p[r], accO[hh * 4 + e], 0, 0, 0);
+      }
+    if (j + 1 < nb) store_block(buf ^ 1);             // the other buffer: nobody reads it during this block
+    __syncthreads();
+  }
+
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (t0 + c16 < s.L) {
+    const float inv = 1.0f / l_run;
+    float* op = (float*)c.out + ((size_t)b * s.L + tq) * s.Hq * D + (size_t)h * D + 16 * g4;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = {round_rt(accO[hh * 4 + 0][r] * inv, s.rnd), round_rt(accO[hh * 4 + 1][r] * inv, s.rnd),
+                         round_rt(accO[hh * 4 + 2][r] * inv, s.rnd), round_rt(accO[hh * 4 + 3][r] * inv, s.rnd)};
+        *(f32x4*)(op + 64 * hh + 4 * r) = v;
+      }
+  }
+}
+
+template <int D, int G>
+int launch_pg32(const AttnCall& c, hipStream_t st) {
+  const AttnShape& s = c.s;
+  const dim3 grid((s.L + QT - 1) / QT, s.B * s.Hkv), block(G * 64);
+  hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G>), grid, block, 0, st, c);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+template <int D>
+int launch_pd32(const AttnCall& c, hipStream_t st) {
+  switch (c.s.Hq / c.s.Hkv) {
+    case 1: return launch_pg32<D, 1>(c, st);
+    case 2: return launch_pg32<D, 2>(c, st);
+    case 4: return launch_pg32<D, 4>(c, st);
+    case 5: return launch_pg32<D, 5>(c, st);
+    case 8: return launch_pg32<D, 8>(c, st);
+  }
+  return fail(MI_ERR_UNSUPPORTED, "attention_prefill: Hq/Hkv must be 1, 2, 4, 5 or 8");
+}
+
 }  // namespace
 
 bool attention_prefill_supported(const AttnShape& s) {
-  if (s.L < 2 || s.act != s.kv || (s.act != MI_BF16 && s.act != MI_F16) || s.rnd != RND_NONE) return false;
+  if (s.L < 2 || s.act != s.kv) return false;
   if (s.Hkv <= 0 || s.Hq % s.Hkv != 0) return false;
   const int G = s.Hq / s.Hkv;
   if (!(G == 1 || G == 2 || G == 4 || G == 5 || G == 8)) return false;
+  if (s.act == MI_F32) return s.D == 64 || s.D == 128;        // (s.rnd = logical rounding of the output, applied at the store)
+  if ((s.act != MI_BF16 && s.act != MI_F16) || s.rnd != RND_NONE) return false;
   return s.D == 32 || s.D == 64 || s.D == 128;
 }
 
 int launch_attention_prefill(const AttnCall& c, hipStream_t st) {
   if (!attention_prefill_supported(c.s)) return fail(MI_ERR_UNSUPPORTED, "attention_prefill: shape / dtype not supported");
   if (c.nsplit != 1) return fail(MI_ERR_INVALID, "attention_prefill: no split-KV");
+  if (c.s.act == MI_F32) return c.s.D == 128 ? launch_pd32<128>(c, st) : launch_pd32<64>(c, st);
   return c.s.act == MI_BF16 ? launch_pt<bf16>(c, st) : launch_pt<f16>(c, st);
 }
 

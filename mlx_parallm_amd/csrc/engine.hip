@@ -107,6 +107,7 @@ struct mi_engine {
   // RMSNorm hand-over between gemm_skinny launches (GemvCall::sq_out / sq_in): the residual linear in front of a norm
   // leaves the rows' sums of squares, the normalised linear behind it uses them instead of an rmsnorm launch
   int opt_norm_handover = 0;    // measured neutral (int4 / int8 +-1 %, Qwen3-14B int4 -3.6 %): off by default
+  int opt_defer_norm = 1;       // float32 activations: RMSNorm row scale applied in the split-K kernel's epilogue (no norm launch)
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
   bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0;
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
@@ -117,6 +118,7 @@ struct mi_engine {
   unsigned seam_base = 0;
   int last_n = 0;                        // rows of the last enqueued step (device-resident token feed)                // value of *d_seam_counter once every enqueued launch has run
   void* xn = nullptr;            // [rows][max(H, I)] normalised activations of the prefill GEMMs
+  void* xs = nullptr; size_t xs_cap = 0;   // [rows][3 K] bf16: float32 activations split three ways (float32-KV prefill)
 };
 
 struct mi_kv {
@@ -313,8 +315,11 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       c.lora_t = e->lora_t; c.lora_t_ld = 128;
       MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
     }
+    // float32 activations without logical rounding (PagedKVCache mode after layer 0): the kernel applies the row scale
+    // of the RMSNorm in its epilogue (gemm_skinny.hip "defer_norm") -- no norm launch, nothing waits for row statistics
+    const bool defer = e->opt_defer_norm && c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && !handed;
     if (handed) { c.sq_in = e->d_sq; c.sq_parts = e->sq_parts; }
-    else if (c.pro == PRO_NORM) {
+    else if (c.pro == PRO_NORM && !defer) {
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
@@ -348,7 +353,17 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {
     // prefill: one MFMA tile GEMM over all rows (the RMSNorm runs as its own row-wise kernel)
     Prof pr(e, prof);
-    if (c.pro == PRO_NORM) {    // (one workgroup per row also here: one L2 round trip per row instead of a wave's 16)
+    if (c.act == MI_F32) {      // PagedKVCache mode: (norm +) exact three-way split of x, then the same tile GEMM over 3 K
+      const size_t need = split3_bytes(rows, f.W.K);
+      if (need > e->xs_cap) {
+        MI_HIP(hipStreamSynchronize(e->stream));
+        hipFree(e->xs); e->xs = nullptr; e->xs_cap = 0;
+        MI_HIP(hipMalloc(&e->xs, need));
+        e->xs_cap = need;
+      }
+      MI_TRY(launch_split3_rows(c.x, c.ldx, c.pro == PRO_NORM ? c.norm_w : nullptr, c.eps, e->xs, (int)rows, f.W.K, e->stream));
+      c.x = e->xs; c.ldx = 3 * f.W.K; c.pro = PRO_NONE;
+    } else if (c.pro == PRO_NORM) {    // (one workgroup per row also here: one L2 round trip per row instead of a wave's 16)
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
     }
@@ -747,7 +762,7 @@ void mi_engine_destroy(mi_engine* e) {
     hipFree(l.in_norm); hipFree(l.post_norm); hipFree(l.q_norm); hipFree(l.k_norm);
     hipFree(l.in_norm32); hipFree(l.post_norm32); hipFree(l.q_norm32); hipFree(l.k_norm32);
   }
-  hipFree(e->final_norm32); hipFree(e->xn);
+  hipFree(e->final_norm32); hipFree(e->xn); hipFree(e->xs);
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
@@ -1136,6 +1151,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "prefill_gemm") { e->opt_prefill_gemm = value != 0; return MI_OK; }
   if (k == "skinny_gemm") { e->opt_skinny_gemm = value != 0; return MI_OK; }
   if (k == "norm_handover") { e->opt_norm_handover = value != 0; return MI_OK; }
+  if (k == "defer_norm") { e->opt_defer_norm = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "tile_weights") {

@@ -44,8 +44,24 @@ struct GemmParams {
   const void* x; int ldx; int M;
   const void* w; int N, K;          // W tile-major; N = rows of W (SWIGLU: gate rows = N/2); K = its reduction length
   int ka;                           // reduction length of x: K, or K/2 when W is a [hi | lo] pair (x is walked twice)
+  int kw;                           // reduction length of W (its row-tile stride): K, or K/3 when x is a [hi | mid | lo]
+                                    // triple of float32 activations (W is walked three times).  k step t multiplies
+                                    // x[.., t mod ka] with W[.., t mod kw]; with ka = 3 K0, kw = 2 K0 the 6 K0 steps meet
+                                    // every (x part, W part) pair once.
+  int out32;                        // outputs / residual stream are float32 (PagedKVCache mode), no 16-bit rounding
   int epi; void* out; int ldo; void* resid; int pair_offset;
 };
+
+// the epilogues in float32 storage (PagedKVCache mode after layer 0: every op produces a float32 array)
+__device__ __forceinline__ void epi32_swiglu(const GemmParams& p, int m, int n, float gt, float up) {
+  const float sig = 1.0f / (1.0f + expf(-gt));
+  const float sl = gt * sig;
+  ((float*)p.out)[(size_t)m * p.ldo + n] = sl * up;
+}
+__device__ __forceinline__ void epi32_plain(const GemmParams& p, int m, int n, float y) {
+  if (p.epi == EPI_STORE) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
+  else { float* h = (float*)p.resid; h[(size_t)m * p.ldo + n] = h[(size_t)m * p.ldo + n] + y; }
+}
 
 // grid: (n blocks, m blocks).  SWIGLU: a block covers 64 gate columns + the 64 matching up columns.
 template <typename AT, bool SWIGLU>
@@ -58,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
   // W tiles, which then stay in the XCD's L2 instead of being re-fetched per block
   const int bm = blockIdx.x, bn = blockIdx.y;
   const int m0 = bm * BM;
-  const int nk = p.K / BK;
+  const int nk = p.K / BK, nkw = p.kw / BK;
   const AT* x = (const AT*)p.x;
 
   // W tiles (16 rows each) of this wave's four N tiles
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int t = min(wtile[nt], ntiles_w - 1);
-        const char* blk = (const char*)p.w + ((size_t)t * (p.K / 32) + (size_t)(ks * 2 + kb)) * 1024;
+        const char* blk = (const char*)p.w + ((size_t)t * (p.kw / 32) + (size_t)((ks % nkw) * 2 + kb)) * 1024;
         breg[set][nt][kb] = *(const u32x4*)(blk + lane * 16);
       }
   };
@@ -158,6 +174,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j) {
           const int n = bn * 64 + wn * 32 + j * 16 + c16;
           if (n >= p.pair_offset) continue;
+          if (p.out32) { epi32_swiglu(p, m, n, acc[mt][j][r], acc[mt][j + 2][r]); continue; }
           const float gt = (float)(AT)acc[mt][j][r], up = (float)(AT)acc[mt][j + 2][r];
           const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
           const float sl = (float)(AT)(gt * sig);
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
         for (int nt = 0; nt < 4; ++nt) {
           const int n = bn * BN + wn * 64 + nt * 16 + c16;
           if (n >= p.N) continue;
+          if (p.out32) { epi32_plain(p, m, n, acc[mt][nt][r]); continue; }
           const float y = (float)(AT)acc[mt][nt][r];
           if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
           else {
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
   const int c16 = lane & 15, g = lane >> 4;
   const int bm = blockIdx.x, bn = blockIdx.y;           // M fastest: co-scheduled blocks share the W tiles in L2
   const int m0 = bm * BM2;
-  const int nk = p.K / BK;
+  const int nk = p.K / BK, nkw = p.kw / BK;
   const AT* x = (const AT*)p.x;
   const int ntiles_w = p.N / 16;
   auto a_img = [&](int buf) { return (AT*)(smem2 + (size_t)buf * A2_BYTES); };
@@ -245,26 +263,26 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
     arow[i] = x + (size_t)min(m0 + row, p.M - 1) * p.ldx + kq * 8;
     if constexpr (!BD) {
       const int s = c >> 7, kb = (c >> 6) & 1, l = c & 63;
-      brow[i] = (const char*)p.w + ((size_t)w_tile_of(s) * (p.K / 32) + (size_t)kb) * 1024 + l * 16;
+      brow[i] = (const char*)p.w + ((size_t)w_tile_of(s) * (p.kw / 32) + (size_t)kb) * 1024 + l * 16;
     }
   }
   const char* bptr[4];                                   // BD: this wave's four N tiles, lane-linear
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) bptr[nt] = (const char*)p.w + (size_t)w_tile_of(wn * 4 + nt) * (p.K / 32) * 1024 + lane * 16;
+  for (int nt = 0; nt < 4; ++nt) bptr[nt] = (const char*)p.w + (size_t)w_tile_of(wn * 4 + nt) * (p.kw / 32) * 1024 + lane * 16;
   auto load_a = [&](int ks) {
     const int ka = (ks * BK) % p.ka;
 #pragma unroll
     for (int i = 0; i < 4; ++i) areg[i] = *(const u32x4*)(arow[i] + ka);
     if constexpr (!BD) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) breg[i] = *(const u32x4*)(brow[i] + (size_t)ks * 2048);
+      for (int i = 0; i < 4; ++i) breg[i] = *(const u32x4*)(brow[i] + (size_t)(ks % nkw) * 2048);
     }
   };
   auto load_bd = [&](int ks, u32x4 (&dst)[2][4]) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) dst[kb][nt] = *(const u32x4*)(bptr[nt] + (size_t)(ks * 2 + kb) * 1024);
+      for (int nt = 0; nt < 4; ++nt) dst[kb][nt] = *(const u32x4*)(bptr[nt] + (size_t)((ks % nkw) * 2 + kb) * 1024);
   };
   auto store_ab = [&](int buf) {
     AT* A = a_img(buf);
@@ -360,6 +378,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j) {
           const int n = bn * 128 + wn * 32 + j * 16 + c16;
           if (n >= p.pair_offset) continue;
+          if (p.out32) { epi32_swiglu(p, m, n, acc[mt][j][r], acc[mt][j + 2][r]); continue; }
           const float gt = (float)(AT)acc[mt][j][r], up = (float)(AT)acc[mt][j + 2][r];
           const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
           const float sl = (float)(AT)(gt * sig);
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
         for (int nt = 0; nt < 4; ++nt) {
           const int n = bn * BN2 + wn * 64 + nt * 16 + c16;
           if (n >= p.N) continue;
+          if (p.out32) { epi32_plain(p, m, n, acc[mt][nt][r]); continue; }
           const float y = (float)(AT)acc[mt][nt][r];
           if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
           else {
@@ -483,6 +503,51 @@ __global__ __launch_bounds__(256) void rmsnorm_row_block_f32_kernel(const float*
   }
 }
 
+
+// float32 activations in front of the tile GEMM (PagedKVCache mode): x (optionally RMS-normalised first, in float32) is
+// split EXACTLY into three 16-bit terms, x = hi + mid + lo (hi = T(x), mid = T(x - hi), lo = T(x - hi - mid): 24
+// mantissa bits), stored side by side as one row [hi | mid | lo] of 3 K elements.  The GEMM then walks W three times
+// (GemmParams::kw): every product is exact in the float32 accumulator, so the result is a float32 dot product in
+// another summation order -- the same arithmetic as the decode step's skinny_kernel<.., X32>.  One workgroup per row.
+template <typename AT>
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* x, int ldx, const float* norm_w, float eps, AT* out,
+                                                          int K) {
+  __shared__ float part[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)row * ldx;
+  float rs = 1.0f;
+  if (norm_w != nullptr) {
+    float ss = 0.f;
+    for (int k = tid * 4; k < K; k += 1024) {
+      const f32x4 v = *(const f32x4*)(xr + k);
+      ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    rs = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)K + eps);
+  }
+  AT* o = out + (size_t)row * 3 * K;
+  for (int k = tid * 4; k < K; k += 1024) {
+    f32x4 v = *(const f32x4*)(xr + k);
+    if (norm_w != nullptr) {
+      const f32x4 wv = *(const f32x4*)(norm_w + k);
+      v.x = (v.x * rs) * wv.x; v.y = (v.y * rs) * wv.y; v.z = (v.z * rs) * wv.z; v.w = (v.w * rs) * wv.w;
+    }
+    AT hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = (AT)v[j];
+      const float r1 = v[j] - (float)hi[j];
+      mid[j] = (AT)r1;
+      lo[j] = (AT)(r1 - (float)mid[j]);
+    }
+    *(uint2*)(o + k) = *(const uint2*)hi;
+    *(uint2*)(o + K + k) = *(const uint2*)mid;
+    *(uint2*)(o + 2 * K + k) = *(const uint2*)lo;
+  }
+}
+
 template <typename AT>
 int launch_rmsnorm_block(const void* x, int ldx, const void* w, void* out, int ldo, int rows, int H, float eps, hipStream_t st) {
   const int np = (H / 8 + 255) / 256;
@@ -509,8 +574,12 @@ bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   const bool q4 = ((W.wk == WK_Q4_BF16 && c.act == MI_BF16) || (W.wk == WK_Q4_F16 && c.act == MI_F16)) && W.group == 64 &&
                   W.K % 128 == 0;                       // through a [hi | lo] 16-bit copy (launch_dequant_q4_hilo)
   const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64;
-  if (!dense && !q4 && !q8) return false;
-  if (W.K % BK != 0 || c.ldx % 8 != 0) return false;
+  // float32 activations on a bf16 model (PagedKVCache mode): x goes through launch_split3_rows first
+  static const bool f32_ok = getenv("MI_GEMM_NO_F32") == nullptr;
+  const bool x32 = f32_ok && c.act == MI_F32 && (W.wk == WK_BF16 || (W.wk == WK_Q4_BF16 && W.group == 64 && W.K % 128 == 0)) &&
+                   W.lora_b[0] == nullptr && W.lora_b[1] == nullptr && c.ldx % 4 == 0 && W.K % 4 == 0;
+  if (!dense && !q4 && !q8 && !x32) return false;
+  if (W.K % BK != 0 || (!x32 && c.ldx % 8 != 0)) return false;
   if (c.epi == EPI_STORE_F32) return false;
   // an adapted matrix: the caller adds the LoRA term to the stored output afterwards (launch_lora_up_add)
   if ((W.lora_b[0] != nullptr || W.lora_b[1] != nullptr) && c.epi != EPI_STORE) return false;
@@ -543,14 +612,29 @@ int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ld
 
 // c.pro must be PRO_NONE here (the caller runs launch_rmsnorm_rows first); rows = total rows of x.
 // int4 weights: `scratch` (>= dequant_hilo_bytes(N, K)) receives the [hi | lo] copy first.
+size_t split3_bytes(size_t rows, int K) { return rows * 3 * (size_t)K * 2; }
+
+int launch_split3_rows(const void* x, int ldx, const void* norm_w, float eps, void* out, int rows, int K, hipStream_t st) {
+  if (K % 4 != 0 || ldx % 4 != 0) return fail(MI_ERR_UNSUPPORTED, "split3_rows: K and the row stride must be multiples of 4");
+  hipLaunchKernelGGL(split3_rows_kernel<bf16>, dim3(rows), dim3(256), 0, st, (const float*)x, ldx, (const float*)norm_w, eps,
+                     (bf16*)out, K);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch) {
   if (c.pro != PRO_NONE) return fail(MI_ERR_INVALID, "gemm_prefill: normalise the rows first");
   GemmParams p{};
-  p.x = c.x; p.ldx = c.ldx; p.M = (int)rows; p.w = W.w; p.N = W.N; p.K = W.K; p.ka = W.K;
+  p.x = c.x; p.ldx = c.ldx; p.M = (int)rows; p.w = W.w; p.N = W.N; p.K = W.K; p.ka = W.K; p.kw = W.K;
   if (wk_is_quant(W.wk)) {
     if (scratch == nullptr) return fail(MI_ERR_INVALID, "gemm_prefill: int4 weights need a dequantisation scratch buffer");
     MI_TRY(launch_dequant_q4_hilo(W, scratch, st));
-    p.w = scratch; p.K = 2 * W.K;
+    p.w = scratch; p.K = 2 * W.K; p.kw = 2 * W.K;
+  }
+  const bool x32 = c.act == MI_F32;        // c.x is the [hi | mid | lo] bf16 image of launch_split3_rows, c.ldx = 3 K
+  if (x32) {
+    if (c.ldx != 3 * W.K) return fail(MI_ERR_INVALID, "gemm_prefill: float32 activations must be split first (launch_split3_rows)");
+    p.ka = 3 * W.K; p.K = (wk_is_quant(W.wk) ? 6 : 3) * W.K; p.out32 = 1;
   }
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
   const bool sw = c.epi == EPI_SWIGLU;
@@ -567,14 +651,14 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
       else { auto k = gemm_tile256_kernel<T, S, true>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * A2_BYTES)); \
         hipLaunchKernelGGL(k, grid2, block2, 2 * A2_BYTES, st, p); } } while (0)
-    if (c.act == MI_BF16) { if (sw) GO256(bf16, true); else GO256(bf16, false); }
+    if (c.act == MI_BF16 || x32) { if (sw) GO256(bf16, true); else GO256(bf16, false); }
     else { if (sw) GO256(f16, true); else GO256(f16, false); }
 #undef GO256
     MI_HIP(hipGetLastError());
     return MI_OK;
   }
   const dim3 grid(((int)rows + BM - 1) / BM, (ncols + (sw ? 64 : BN) - 1) / (sw ? 64 : BN)), block(256);
-  if (c.act == MI_BF16) {
+  if (c.act == MI_BF16 || x32) {
     if (sw) hipLaunchKernelGGL((gemm_tile_kernel<bf16, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_tile_kernel<bf16, false>), grid, block, 0, st, p);
   } else {

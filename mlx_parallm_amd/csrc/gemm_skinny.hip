@@ -65,6 +65,13 @@ struct SkinnyParams {
   const float* sq_in; int sq_parts;   // consumer: the producer's partial sums and their count
   const void* norm_w; float eps;   //           x -> w * T(x * rsqrt(mean(x^2) + eps)) while staging
   int rnd;                         // float32 activations: logical rounding of the outputs (RND_*)
+  // float32 activations, RMSNorm in front (X32 instantiations only): y = rs[m] * sum_k (x[m][k] w_norm[k]) W[n][k] -- the
+  // row scale rs = rsqrt(mean(x^2) + eps) is a per-row factor of the whole dot product, so it is applied in the EPILOGUE
+  // and nothing at the head of the launch waits for the row statistics: x is multiplied by w_norm while it is staged,
+  // its squares are summed on the way, the K slices' sums meet with the partial tiles.  In float32 this differs from
+  // w * (x * rs) by one rounding per element (~6e-8 relative); rounded (layer-0) calls keep the separate norm launch.
+  int defer_norm;
+  float* sqws;                     // [tile groups][ksplit][16 MT] row sums of squares of the K slices (ksplit > 1)
   int ntiles;        // 16-row tiles (tile pairs for SwiGLU)
   int ksplit;        // workgroups per tile group along K
   int nchunks;       // ceil(K / 256)
@@ -170,27 +177,45 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // over x.  (Letting every workgroup compute the statistics itself from x was measured slower than the launch.)
   __shared__ float rs_sh[16];
   const bool norm = (MT == 1) && p.sq_in != nullptr;
-  u32x4 xr[MT], xw[MT], xr2[X32 ? MT : 1];
+  u32x4 xr[MT], xw[MT], xr2[X32 ? MT : 1], xnw[X32 ? MT : 1], xnw2[X32 ? MT : 1];
+  float sqacc[X32 ? MT : 1];
+#pragma unroll
+  for (int i = 0; i < (X32 ? MT : 1); ++i) sqacc[i] = 0.f;
+  const bool dn = X32 && p.defer_norm != 0;
   auto load_x = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int k = c * SK_KC + xk[i];
       xr[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0));
-      if constexpr (X32) xr2[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0) + 4);
+      if constexpr (X32) {
+        xr2[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0) + 4);
+        if (dn) {
+          xnw[i] = *(const u32x4*)((const float*)p.norm_w + (k < p.K ? k : 0));
+          xnw2[i] = *(const u32x4*)((const float*)p.norm_w + (k < p.K ? k : 0) + 4);
+        }
+      }
       if constexpr (MT == 1) {
         if (norm) xw[i] = *(const u32x4*)((const AT*)p.norm_w + (k < p.K ? k : 0));
       }
     }
   };
-  auto store_x = [&](int c, unsigned char* buf) {
+  auto store_x = [&](int c, unsigned char* buf, bool fresh = true) {   // fresh: first time this chunk is staged (its squares count)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const bool ok = xm[i] && (c * SK_KC + xk[i] < p.K);
       if constexpr (X32) {
         const u32x4 z4 = {0u, 0u, 0u, 0u};
         const u32x4 f0 = ok ? xr[i] : z4, f1 = ok ? xr2[i] : z4;
-        const float xf[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
-                             __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
+        float xf[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                       __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
+        if (dn) {                                // deferred RMSNorm: squares of the raw x, then x * w_norm
+          const float wf[8] = {__uint_as_float(xnw[i].x), __uint_as_float(xnw[i].y), __uint_as_float(xnw[i].z), __uint_as_float(xnw[i].w),
+                               __uint_as_float(xnw2[i].x), __uint_as_float(xnw2[i].y), __uint_as_float(xnw2[i].z), __uint_as_float(xnw2[i].w)};
+          float ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ss = fmaf(xf[j], xf[j], ss); xf[j] *= wf[j]; }
+          if (fresh) sqacc[i] += ss;
+        }
         AT hi[8], mid[8], lo[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -401,10 +426,34 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         __builtin_amdgcn_sched_barrier(0);
         issue(slot, unit + UK);
         __builtin_amdgcn_sched_barrier(0);
-        if (i == UPC / 2) store_x(cn, nxt);
+        if (i == UPC / 2) store_x(cn, nxt, cc + 1 < c1);   // (past the slice's end the last chunk is staged again, unused)
       }
       __syncthreads();                            // the next chunk's fragments are complete; this chunk's are free
       unsigned char* t = cur; cur = nxt; nxt = t;
+    }
+  }
+
+  // ================= deferred RMSNorm: this slice's sum of x^2 per row, in a fixed order (8 lanes of a piece by DPP,
+  // then the 4 k-groups of the chunk through LDS)
+  __shared__ float rs_row[32];
+  float slice_sq = 0.f;                          // threads < MB: the slice's sum for row tid
+  if constexpr (X32) {
+    if (dn) {
+      float* sq4 = (float*)smem;                 // [4][MB] (the activation buffers are free: the slice loop ended on a barrier)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float v = lane8_sum(sqacc[i]);
+        const int r = (tid + i * (SK_NW * 64)) >> 3;
+        if ((tid & 7) == 0) sq4[(r / MB) * MB + (r % MB)] = v;
+      }
+      __syncthreads();
+      if (tid < MB) slice_sq = (sq4[tid] + sq4[MB + tid]) + (sq4[2 * MB + tid] + sq4[3 * MB + tid]);
+      if (p.ksplit > 1) {
+        if (tid < MB) __hip_atomic_store(&p.sqws[((size_t)grp * p.ksplit + s) * MB + tid], slice_sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (tid < MB) rs_row[tid] = 1.0f / sqrtf(slice_sq / (float)p.K + p.eps);
+        __syncthreads();
+      }
     }
   }
 
@@ -437,6 +486,17 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
     }
     __syncthreads();
     if (!last_sh) return;
+    if constexpr (X32) {
+      if (dn) {                                  // the slices' sums of squares, in slice order
+        if (tid < MB) {
+          float tot = 0.f;
+          for (int s2 = 0; s2 < p.ksplit; ++s2)
+            tot += __hip_atomic_load(&p.sqws[((size_t)grp * p.ksplit + s2) * MB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rs_row[tid] = 1.0f / sqrtf(tot / (float)p.K + p.eps);
+        }
+        __syncthreads();
+      }
+    }
     if (valid) {
 #pragma unroll
       for (int a = 0; a < NA; ++a)
@@ -469,11 +529,13 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
     for (int r = 0; r < 4; ++r) {
       const int m = mt * 16 + g * 4 + r;
       if (m >= p.M || !valid) continue;
-      const float y0 = acc[0][mt][r];
+      float y0 = acc[0][mt][r];
       if constexpr (X32) {                        // float32 storage, run-time logical rounding (gemv_v1.hip's epilogue)
         float* o32 = (float*)p.out;
+        const float rsm = dn ? rs_row[m] : 1.0f;
+        y0 *= rsm;
         if constexpr (SWIGLU) {
-          const float gt = round_rt(y0, p.rnd), up = round_rt(acc[NA - 1][mt][r], p.rnd);
+          const float gt = round_rt(y0, p.rnd), up = round_rt(acc[NA - 1][mt][r] * rsm, p.rnd);
           const float sig = round_rt(1.0f / (1.0f + expf(-gt)), p.rnd);
           const float sl = round_rt(gt * sig, p.rnd);
           o32[(size_t)m * p.ldo + n] = round_rt(sl * up, p.rnd);
@@ -570,6 +632,8 @@ SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
     if (s == 1 || t < best * 0.97) { best = t; pl.ksplit = s; }            // a larger split has to earn its partials
   }
   pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024 : 0;
+  if (pl.ksplit > 1 && c.act == MI_F32 && c.pro == PRO_NORM)       // deferred RMSNorm: the K slices' row sums of squares
+    pl.ws_bytes += (size_t)pl.ngroups * pl.ksplit * 16 * pl.mt * sizeof(float);
   return pl;
 }
 
@@ -663,12 +727,14 @@ int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows) { retur
 
 // c.pro must be PRO_NONE (normalise first); `ws` holds gemm_skinny_ws_bytes(), `ctr` gemm_skinny_groups() zeroed words
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr, int ksplit) {
-  if (c.pro != PRO_NONE && !(rows <= 16 && c.sq_in != nullptr && c.sq_parts > 0))
+  const bool defer_norm = c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && c.norm_w != nullptr;
+  if (c.pro != PRO_NONE && !defer_norm && !(rows <= 16 && c.sq_in != nullptr && c.sq_parts > 0))
     return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first (or hand over the row sums of squares)");
   SkinnyPlan pl = skinny_plan(W, c, rows);
   if (ksplit > 0) {
     pl.ksplit = std::min(ksplit, pl.nchunks);
     pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024 : 0;
+    if (pl.ksplit > 1 && defer_norm) pl.ws_bytes += (size_t)pl.ngroups * pl.ksplit * 16 * pl.mt * sizeof(float);
   }
   if (pl.ksplit > 1 && (ws == nullptr || ctr == nullptr)) return fail(MI_ERR_INVALID, "gemm_skinny: workspace missing");
   SkinnyParams p{};
@@ -680,6 +746,8 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   p.norm_w = c.norm_w; p.eps = c.eps; p.rnd = c.rnd;
   p.ntiles = pl.ntiles; p.ksplit = pl.ksplit; p.nchunks = pl.nchunks;
   p.ws = (float*)ws; p.ctr = ctr;
+  p.defer_norm = defer_norm ? 1 : 0;
+  p.sqws = (defer_norm && pl.ksplit > 1) ? (float*)((char*)ws + (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024) : nullptr;
   p.lora_t = c.lora_t; p.lora_t_ld = c.lora_t_ld;
   p.lora_b0 = W.lora_b[0]; p.lora_b1 = W.lora_b[1];
   p.lora_row0_0 = W.lora_row0[0]; p.lora_n_0 = W.lora_n[0]; p.lora_rank_0 = W.lora_rank[0]; p.lora_scale_0 = W.lora_scale[0];

@@ -5,7 +5,7 @@ The small goldens (make_golden.py) pin the decode path on 64..128-wide models.  
 shapes: Mistral-7B (H 4096, 32 q / 8 kv heads x 128, I 14336, V 32000) and Qwen3-14B (H 5120, 40 / 8 heads x 128 with
 q/k norms, I 17408, V 151936), truncated to 2 decoder blocks so that the NumPy oracle finishes in minutes; bf16, int4
 g64 and int4 + a rank-16 LoRA adapter on q/v; both KV modes (PagedKVCache float32 = the reference's default numerics,
-BatchedKVCache = model dtype); batch 8 with a 1024-token prompt decoded to KV length 1101 (the regime of the bench,
+BatchedKVCache = model dtype); batch 8 with a 1024-token prompt decoded to KV length 1100 (the regime of the bench,
 including the second 256-key round of the split-KV decode attention), plus a batch-32 and a ragged batch-64 case
 (configs 4 and 5).  "parity unpinned": like every golden here these are outputs of the build's own oracle, not of MLX.
 

@@ -77,6 +77,30 @@ def test_prefill_and_decode_logits(tiny_dirs, name, mode):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
+@pytest.mark.parametrize("B,L0", [(4, 40), (5, 64)])
+def test_float32_kv_prefill_through_the_tile_gemm(tiny_dirs, name, B, L0):
+    """PagedKVCache mode, prompts of >= 32 rows in all: float32 activations are split exactly three ways
+    (split3_rows_kernel) and go through the MFMA tile GEMM (128- and 256-row tiles) and the float32 MFMA attention;
+    all-position logits and the decode steps behind them against the oracle, float32 tolerances."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    toks = _left_pad_prompts(cfg, B, L0)
+    kv = model.engine.new_kv(B, capacity=L0 + 8, kv_dtype="float32")
+    cache = ref.make_cache(B, paged=True)
+    got = model.engine.forward(toks, kv, all_positions=True)
+    want = ref(toks, cache=cache)
+    tol = 4e-3          # layer 0 of this mode still rounds to the 16-bit dtype: rare 1-ulp flips (see test_gpu_golden_wide.py)
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert np.sqrt(((got - want) ** 2).mean()) <= 2e-4
+    nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    for _ in range(2):
+        got = model.engine.forward(nxt.astype(np.int32), kv)
+        want = ref(nxt, cache=cache)[:, -1]
+        assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+        nxt = np.argmax(want, axis=-1)[:, None]
+    model.engine.close()
+
+
 def _teacher_forced_greedy(model, ref, cfg, kvd, paged, B, L0, steps, margin_eps):
     toks = _left_pad_prompts(cfg, B, L0)
     kv = model.engine.new_kv(B, capacity=L0 + steps + 1, kv_dtype=kvd)

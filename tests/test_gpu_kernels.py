@@ -273,8 +273,7 @@ def test_fused_decode_attention(act, Hq, Hkv, D, qk_norm, variant):
     """mi_op_attention_decode: q/k norm + RoPE + KV append + attention + split combine in one launch,
     MFMA (variant 0, 16-bit caches) and VALU (variant 1) kernels: ragged per-row context lengths up to
     eight 256-key rounds, 1 / 3 / 4 / 8 splits; the cache must receive exactly the new K / V row."""
-    if act == "float32" and variant == 0:
-        pytest.skip("the MFMA kernel is for 16-bit caches; float32 runs the VALU kernel either way")
+    # (float32 caches: variant 0 is the v_mfma_f32_16x16x4_f32 kernel for head_dim 64 / 128, the VALU kernel otherwise)
     # 1023 / 1024 / 1100: the bench's regime (one full 4 x 256-key pass, then a second, nearly empty round per
     # workgroup); 2047: eight rounds
     B, cap, max_pos = 8, 2064, 2112
