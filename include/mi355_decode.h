@@ -173,6 +173,16 @@ int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, in
  * length) while the other slots keep decoding in their own steps.  Results come back in `rows` order. */
 int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, const int32_t* tokens_in, int L,
                          const mi_sample_params* sp, int64_t* ticket);
+/* Chunked prefill co-scheduled with the live decode rows (the reference admits a request only between batches and
+ * prefills it alone, server/main.py:1404-1726): ONE pass over the weights for n segments that advance by different
+ * numbers of tokens.  Segment i appends lens[i] >= 1 tokens to cache row rows[i] (distinct rows); the one-token
+ * segments (decode rows) must come first; `tokens` is the concatenation (sum of lens).  want[i] != 0: sample a token
+ * from the logits after the segment's last position (every decode row, and the LAST chunk of a prompt); want[i] == 0:
+ * an inner chunk, no logits.  mi_step_wait then returns the results of the wanted segments, in segment order (the
+ * ticket's batch = their count; row_temperature / row_top_p, if given, have one entry per wanted segment).  Explicit
+ * tokens only: the device-resident token feed of mi_step_enqueue(_rows) restarts after a mixed step. */
+int mi_step_enqueue_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* lens, const int32_t* want, int n,
+                          const int32_t* tokens, const mi_sample_params* sp, int64_t* ticket);
 /* Forget the contents of one row (its length becomes 0); ordered behind the steps already enqueued. */
 int mi_kv_reset_row(mi_kv* kv, int row);
 /* Block until `ticket` has finished; copy out its results (same meaning as mi_decode_sample). */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mi_score_tokens": (C.c_int, [_P, _P, _I32P, _I32P, C.c_int, C.c_int, C.POINTER(SampleParams), _F32P, _I32P, _F32P]),
     "mi_step_enqueue": (C.c_int, [_P, _P, _I32P, C.c_int, C.c_int, C.POINTER(SampleParams), C.POINTER(C.c_int64)]),
     "mi_step_enqueue_rows": (C.c_int, [_P, _P, _I32P, C.c_int, _I32P, C.c_int, C.POINTER(SampleParams), C.POINTER(C.c_int64)]),
+    "mi_step_enqueue_mixed": (C.c_int, [_P, _P, _I32P, _I32P, _I32P, C.c_int, _I32P, C.POINTER(SampleParams), C.POINTER(C.c_int64)]),
     "mi_kv_reset_row": (C.c_int, [_P, C.c_int]),
     "mi_step_wait": (C.c_int, [_P, C.c_int64, _I32P, _F32P, _F32P, _I32P, _F32P]),
     "mi_profile_select": (C.c_int, [_P, C.c_char_p]),

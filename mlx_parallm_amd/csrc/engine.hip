@@ -81,6 +81,7 @@ struct mi_engine {
   float* logits = nullptr; float* lora_t = nullptr;
   int32_t* d_tokens = nullptr; size_t d_tokens_cap = 0;
   int32_t* d_forced = nullptr; size_t d_forced_cap = 0;   // mi_score_tokens targets
+  int32_t* d_gather = nullptr;                            // token positions whose hidden state feeds the head (mixed steps)
   float* d_rowpar = nullptr; size_t d_rowpar_cap = 0;     // per-row temperature | top_p of the current step
   void* deq_scratch = nullptr; size_t deq_cap = 0;        // [hi | lo] 16-bit copy of one int4 matrix (prefill GEMM)
   void* sk_ws = nullptr; size_t sk_ws_cap = 0;            // split-K partial tiles of gemm_skinny.hip
@@ -642,6 +643,122 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
   return MI_OK;
 }
 
+
+// ---- one pass over the weights for rows that advance by DIFFERENT numbers of tokens (chunked prefill co-scheduled with
+// the live decode rows): segment i = lens[i] tokens of cache row rows[i].  The decode rows (lens == 1) come first in
+// the token buffer and share one decode-attention launch; every longer segment is one prefill-attention call on its
+// own row.  All linear layers run ONCE over the concatenated tokens (tile GEMM from 32 tokens up), which is the point:
+// the weights of a layer are read once for the 7 live sequences AND the 256-token chunk of an arriving prompt.
+// Logits are produced for the last token of the segments with want[i] != 0, in segment order.
+int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* lens, const int32_t* want, int n, int n_out) {
+  const mi_model_desc& d = e->d;
+  const bool quirk = kv->quirk;
+  const int act = quirk ? MI_F32 : d.act_dtype;
+  const size_t es = dtype_size(act);
+  const int rndT = quirk ? (d.act_dtype == MI_BF16 ? RND_BF16 : RND_F16) : RND_NONE;
+  const int H = d.hidden_size, D = d.head_dim, Hq = d.num_heads, Hkv = d.num_kv_heads, I = d.intermediate_size;
+  const int nqkv = (Hq + 2 * Hkv) * D;
+  hipStream_t st = e->stream;
+  int nd = 0;                                    // decode rows: the leading segments of length 1
+  while (nd < n && lens[nd] == 1) ++nd;
+  size_t R = 0;
+  std::vector<size_t> tok0(n);
+  for (int i = 0; i < n; ++i) {
+    if (i >= nd && lens[i] == 1) return fail(MI_ERR_INVALID, "mixed step: one-token segments must come first");
+    if (kv->h_off[rows[i]] + lens[i] > kv->cap || kv->h_off[rows[i]] + lens[i] > d.max_positions)
+      return fail(MI_ERR_INVALID, "mixed step: KV capacity / max_positions exceeded (call mi_kv_reserve)");
+    tok0[i] = R; R += (size_t)lens[i];
+  }
+  e->cur_L = R == (size_t)nd ? 1 : 2;            // only decode rows: the decode step's kernels; else the prefill path's
+  e->sq_valid = false;
+  if (!kv->d_rows) MI_HIP(hipMalloc(&kv->d_rows, kv->B * sizeof(int32_t)));
+  MI_HIP(hipMemcpyAsync(kv->d_rows, rows, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+
+  { Prof pr(e, "embed");
+    EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
+    MI_TRY(launch_embed(e->embed.W, ec, st)); }
+
+  const size_t layer_elems = (size_t)kv->B * Hkv * kv->cap * D;
+  const size_t kes = dtype_size(kv->dtype);
+  const int nsplit = nd > 0 ? choose_nsplit(kv, nd, Hkv, 1, rows) : 1;
+  if (nsplit > 1 && (kv->partial == nullptr || kv->partial_splits < nsplit)) {
+    MI_HIP(hipStreamSynchronize(st));
+    hipFree(kv->partial);
+    MI_HIP(hipMalloc(&kv->partial, (size_t)kv->B * Hq * 16 * (D + 2) * sizeof(float)));
+    kv->partial_splits = 16;
+  }
+  for (int li = 0; li < d.num_layers; ++li) {
+    LayerW& lw = e->layers[li];
+    const bool w32 = quirk && d.act_dtype != MI_F32;
+    const void* post_norm = w32 ? lw.post_norm32 : lw.post_norm;
+    const void* q_norm = w32 ? lw.q_norm32 : lw.q_norm;
+    const void* k_norm = w32 ? lw.k_norm32 : lw.k_norm;
+    const int rnd = (quirk && li == 0) ? rndT : RND_NONE;
+    { GemvCall c; c.x = e->h; c.ldx = H; c.act = act; c.rnd = rnd; c.pro = PRO_NORM;
+      c.norm_w = w32 ? lw.in_norm32 : lw.in_norm; c.eps = d.rms_norm_eps; c.epi = EPI_STORE; c.out = e->qkv; c.ldo = nqkv;
+      MI_TRY(gemv_rows(e, lw.qkv, c, R, es, es, "gemv_qkv")); }
+    void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
+    void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
+    if (nd > 0) {                                // the decode rows: tokens [0, nd)
+      AttnShape s{nd, 1, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, kv->d_rows};
+      if (e->opt_fused_attn && attention_decode_supported(s)) {
+        AttnDecodeCall ac{s, e->qkv, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab,
+                          e->attn, 1.0f / sqrtf((float)D), RND_NONE, nsplit, kv->partial, kv->counters,
+                          e->opt_attn_mfma ? 0 : 1};
+        if (nd <= 32) {
+          ac.n_host_off = nd;
+          for (int b = 0; b < nd; ++b) { ac.host_row[b] = rows[b]; ac.host_off[b] = kv->h_off[rows[b]]; }
+        }
+        Prof pr(e, "attn");
+        MI_TRY(launch_attention_decode(ac, st));
+      } else {
+        RopeAppendCall rc{s, e->qkv, e->q, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab, d.max_positions};
+        MI_TRY(launch_rope_append(rc, st));
+        AttnShape sa = s; sa.rnd = RND_NONE;
+        AttnCall ac{sa, e->q, kc, vc, kv->d_off, e->attn, 1.0f / sqrtf((float)D), nsplit, kv->partial, e->opt_attn_mfma ? 0 : 1};
+        MI_TRY(launch_attention(ac, st));
+      }
+    }
+    for (int i = nd; i < n; ++i) {               // every chunk: rope + append + causal attention on its own row
+      AttnShape s{1, lens[i], Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, kv->d_rows + i};
+      const void* qkv_i = (const char*)e->qkv + tok0[i] * (size_t)nqkv * es;
+      void* q_i = (char*)e->q + tok0[i] * (size_t)Hq * D * es;
+      void* o_i = (char*)e->attn + tok0[i] * (size_t)Hq * D * es;
+      RopeAppendCall rc{s, qkv_i, q_i, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab, d.max_positions};
+      MI_TRY(launch_rope_append(rc, st));
+      AttnShape sa = s; sa.rnd = RND_NONE;
+      AttnCall ac{sa, q_i, kc, vc, kv->d_off, o_i, 1.0f / sqrtf((float)D), 1, nullptr, e->opt_attn_mfma ? 0 : 1};
+      MI_TRY(launch_attention(ac, st));
+    }
+    { GemvCall co; co.x = e->attn; co.ldx = Hq * D; co.act = act; co.rnd = RND_NONE; co.epi = EPI_RESID; co.resid = e->h; co.ldo = H;
+      MI_TRY(gemv_rows(e, lw.o, co, R, es, es, "gemv_o"));
+      GemvCall cg; cg.x = e->h; cg.ldx = H; cg.act = act; cg.rnd = RND_NONE; cg.pro = PRO_NORM; cg.norm_w = post_norm;
+      cg.eps = d.rms_norm_eps; cg.epi = EPI_SWIGLU; cg.out = e->act; cg.ldo = I; cg.pair_offset = I;
+      MI_TRY(gemv_rows(e, lw.gate_up, cg, R, es, es, "gemv_gate_up"));
+      GemvCall c; c.x = e->act; c.ldx = I; c.act = act; c.rnd = RND_NONE; c.epi = EPI_RESID; c.resid = e->h; c.ldo = H;
+      MI_TRY(gemv_rows(e, lw.down, c, R, es, es, "gemv_down")); }
+  }
+  if (n_out > 0) {                               // hidden states of the wanted positions -> compact rows -> head
+    std::vector<int32_t> idx;
+    for (int i = 0; i < n; ++i) if (want[i]) idx.push_back((int32_t)(tok0[i] + lens[i] - 1));
+    if (!e->d_gather) MI_HIP(hipMalloc(&e->d_gather, 4096 * sizeof(int32_t)));
+    if (idx.size() > 4096) return fail(MI_ERR_INVALID, "mixed step: too many sampled rows");
+    MI_HIP(hipMemcpyAsync(e->d_gather, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MI_TRY(launch_gather_rows(e->h, (size_t)H * es, e->d_gather, (int)idx.size(), e->xn, st));
+    const FusedLinear& head = d.tie_word_embeddings ? e->embed : e->lm_head;
+    GemvCall c; c.act = act; c.rnd = RND_NONE; c.pro = PRO_NORM; c.norm_w = (quirk && d.act_dtype != MI_F32) ? e->final_norm32 : e->final_norm;
+    c.eps = d.rms_norm_eps; c.epi = EPI_STORE_F32; c.out = e->logits; c.ldo = d.vocab_size; c.x = e->xn; c.ldx = H;
+    const int keep_L = e->cur_L; e->cur_L = 1;   // the few sampled rows go through the decode step's head kernel
+    const int rc_head = gemv_rows(e, head, c, idx.size(), es, sizeof(float), "gemv_head");
+    e->cur_L = keep_L;
+    MI_TRY(rc_head);
+  }
+  if (nd > 0) MI_TRY(launch_advance_offsets(kv->d_off, kv->d_rows, nd, 1, st));
+  for (int i = nd; i < n; ++i) MI_TRY(launch_advance_offsets(kv->d_off, kv->d_rows + i, 1, lens[i], st));
+  for (int i = 0; i < n; ++i) kv->h_off[rows[i]] += lens[i];
+  return MI_OK;
+}
+
 int check_call(mi_engine* e, mi_kv* kv, int B, int L) {
   if (!e || !kv) return fail(MI_ERR_INVALID, "null handle");
   if (!e->finalized) return fail(MI_ERR_INVALID, "engine not finalized");
@@ -765,7 +882,7 @@ void mi_engine_destroy(mi_engine* e) {
   hipFree(e->final_norm32); hipFree(e->xn); hipFree(e->xs);
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
-  hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced);
+  hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced); hipFree(e->d_gather);
   hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
   hipFree(e->sk_ws); hipFree(e->sk_ctr); hipFree(e->d_sq);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
@@ -1088,6 +1205,46 @@ int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, co
     MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)n * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)n * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
   }
+  MI_HIP(hipEventRecord(s.ev, st));
+  *ticket = t;
+  return MI_OK;
+}
+
+int mi_step_enqueue_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* lens, const int32_t* want, int n,
+                          const int32_t* tokens, const mi_sample_params* sp, int64_t* ticket) {
+  if (!e || !kv || !rows || !lens || !want || !tokens) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(check_params(sp));
+  if (n < 1 || n > kv->B) return fail(MI_ERR_INVALID, "mi_step_enqueue_mixed: n must be in [1, batch of the kv]");
+  size_t R = 0; int n_out = 0;
+  for (int i = 0; i < n; ++i) {
+    if (rows[i] < 0 || rows[i] >= kv->B) return fail(MI_ERR_INVALID, "mi_step_enqueue_mixed: row out of range");
+    for (int j = 0; j < i; ++j) if (rows[j] == rows[i]) return fail(MI_ERR_INVALID, "mi_step_enqueue_mixed: duplicate row");
+    if (lens[i] < 1) return fail(MI_ERR_INVALID, "mi_step_enqueue_mixed: every segment needs at least one token");
+    R += (size_t)lens[i]; n_out += want[i] ? 1 : 0;
+  }
+  MI_TRY(check_call(e, kv, kv->B, 1));
+  if (!ticket) return fail(MI_ERR_INVALID, "null ticket");
+  if (sp && (sp->row_temperature != nullptr) != (sp->row_top_p != nullptr)) return fail(MI_ERR_INVALID, "row_temperature and row_top_p come together");
+  MI_TRY(ensure_workspace(e, R, (size_t)std::max(n_out, 1), std::max(n, kv->B)));
+  hipStream_t st = e->stream;
+  for (size_t i = 0; i < R; ++i)
+    if (tokens[i] < 0 || tokens[i] >= e->d.vocab_size) return fail(MI_ERR_INVALID, "token id out of range");
+  MI_HIP(hipMemcpyAsync(e->d_tokens, tokens, R * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  MI_TRY(forward_mixed(e, kv, rows, lens, want, n, n_out));
+  const int64_t t = e->next_ticket++;
+  Slot& s = e->slots[t % NSLOT];
+  s.B = n_out; s.topk = sp ? sp->top_logprobs : 0; s.ticket = t;
+  if (n_out > 0) {
+    MI_TRY(run_sample(e, n_out, sp));
+    MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(s.logprob, e->d_logprob, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(s.prob0, e->d_prob0, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (s.topk > 0) {
+      MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)n_out * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)n_out * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+  }
+  e->last_n = -1;                                // the device-resident token feed does not survive a mixed step
   MI_HIP(hipEventRecord(s.ev, st));
   *ticket = t;
   return MI_OK;

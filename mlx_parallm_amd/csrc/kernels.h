@@ -232,6 +232,8 @@ struct SampleCall {
 int launch_sample(const SampleCall& c, hipStream_t st);
 
 int launch_advance_offsets(int32_t* offsets, const int32_t* rows, int B, int L, hipStream_t st);
+// dst[i][:] = src[idx[i]][:] for n rows of row_bytes (a multiple of 16) each; idx on the device
+int launch_gather_rows(const void* src, size_t row_bytes, const int32_t* idx, int n, void* dst, hipStream_t st);
 int launch_rope_tables(float* cos_tab, float* sin_tab, int max_pos, int D, float base, float scale,
                        hipStream_t st);
 int launch_convert(const void* src, int src_dt, void* dst, int dst_dt, size_t n, hipStream_t st);

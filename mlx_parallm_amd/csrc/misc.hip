@@ -529,6 +529,20 @@ int launch_sample(const SampleCall& c, hipStream_t st) {
   return MI_OK;
 }
 
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u128* src, size_t row_vecs, const int32_t* idx, u128* dst) {
+  const u128* s = src + (size_t)idx[blockIdx.x] * row_vecs;
+  u128* d = dst + (size_t)blockIdx.x * row_vecs;
+  for (size_t i = threadIdx.x; i < row_vecs; i += 256) d[i] = s[i];
+}
+
+int launch_gather_rows(const void* src, size_t row_bytes, const int32_t* idx, int n, void* dst, hipStream_t st) {
+  if (row_bytes % 16 != 0) return fail(MI_ERR_UNSUPPORTED, "gather_rows: rows must be multiples of 16 bytes");
+  if (n <= 0) return MI_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, st, (const u128*)src, row_bytes / 16, idx, (u128*)dst);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 int launch_advance_offsets(int32_t* offsets, const int32_t* rows, int B, int L, hipStream_t st) {
   hipLaunchKernelGGL(advance_offsets_kernel, dim3(1), dim3(64 * ((B + 63) / 64)), 0, st, offsets, rows, B, L);
   MI_HIP(hipGetLastError());

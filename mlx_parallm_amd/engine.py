@@ -303,6 +303,27 @@ class Engine:
                                              C.byref(sp.c), C.byref(ticket)))
         return int(ticket.value)
 
+    def step_enqueue_mixed(self, kv: KVCache, rows, token_lists, want=None, sample: Optional[SampleArgs] = None) -> int:
+        """``mi_step_enqueue_mixed``: one pass over the weights for rows that advance by different numbers of tokens --
+        the live decode rows (one token each, listed first) and chunks of arriving prompts.  ``token_lists[i]`` = the
+        tokens appended to cache row ``rows[i]``; ``want[i]`` (default: all) = sample after the segment's last token.
+        ``step_wait(ticket, n_wanted)`` returns the wanted segments' results in order."""
+        sp = sample or SampleArgs()
+        r = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1)
+        lens = np.ascontiguousarray([len(t) for t in token_lists], dtype=np.int32)
+        if len(lens) != len(r) or len(r) == 0:
+            raise ValueError("step_enqueue_mixed: one token list per row")
+        w = np.ones(len(r), dtype=np.int32) if want is None else np.ascontiguousarray(want, dtype=np.int32).reshape(-1)
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in token_lists]))
+        offs = kv.offsets
+        kv.ensure(max(offs[int(i)] + int(n) for i, n in zip(r, lens)))
+        ticket = C.c_int64(-1)
+        I32 = C.POINTER(C.c_int32)
+        L.check(L.lib().mi_step_enqueue_mixed(self._h, kv._h, r.ctypes.data_as(I32), lens.ctypes.data_as(I32),
+                                              w.ctypes.data_as(I32), len(r), toks.ctypes.data_as(I32), C.byref(sp.c),
+                                              C.byref(ticket)))
+        return int(ticket.value)
+
     def step_wait(self, ticket: int, batch_size: int, top_logprobs: int = 0):
         B = int(batch_size)
         toks = np.empty(B, dtype=np.int32)

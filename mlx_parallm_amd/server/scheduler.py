@@ -53,6 +53,8 @@ class Sequence:
         self.last_token = -1
         self.t_submit = time.perf_counter()
         self.cancelled = False
+        self.prefill_pos = 0               # prompt tokens already in the KV cache (chunked prefill)
+        self.prefilled = False             # the whole prompt is in the cache and the first token has been sampled
 
     def cancel(self) -> None:
         """Ask the scheduler to drop this sequence (client gone / request timed out): it stops taking decode steps
@@ -62,7 +64,7 @@ class Sequence:
 
 class ContinuousScheduler:
     def __init__(self, model, tokenizer, max_slots: int = 8, kv_dtype: Optional[str] = None, capacity: int = 1024,
-                 metrics=None):
+                 metrics=None, chunk_tokens: int = 256):
         from ..engine import SampleArgs      # noqa: F401  (fail early if the library is missing)
         from ..utils import DEFAULT_KV_DTYPE
 
@@ -83,6 +85,12 @@ class ContinuousScheduler:
         self.steps = 0                     # decode steps executed
         self.prefills = 0
         self.max_rows_seen = 0
+        # chunked prefill: an arriving prompt enters the cache in chunks of at most `chunk_tokens` tokens, each chunk in
+        # the SAME pass over the weights as the live rows' decode step (engine.step_enqueue_mixed).  0 = the older
+        # behaviour: the whole prompt is prefilled alone while the live rows wait.
+        self.chunk_tokens = int(chunk_tokens) if hasattr(model.engine, "step_enqueue_mixed") else 0
+        self.mixed_steps = 0               # steps that carried prompt chunks next to decode rows
+        self.chunks = 0
 
     # ------------------------------------------------------------------ client side (any thread)
     def submit(self, prompt_ids, max_tokens: int, temp: float, top_p: float, sink: Sink) -> Sequence:
@@ -192,12 +200,59 @@ class ContinuousScheduler:
             self._finish(seq, "length")
             return
         self.kv.reset_row(slot)
+        if self.chunk_tokens > 0:                 # the prompt enters the cache chunk by chunk, inside the decode steps
+            seq.prefill_pos = 0
+            return
         t0 = time.perf_counter()
         res = eng.step_wait(eng.step_enqueue_rows(self.kv, [slot], seq.prompt[None, :], self._sample_args([seq])), 1)
         self.prefills += 1
+        seq.prefill_pos, seq.prefilled = len(seq.prompt), True
         if self.metrics is not None:
             self.metrics.record_throughput({"prompt_tokens": float(len(seq.prompt)), "prompt_time": time.perf_counter() - t0})
         self._on_token(seq, int(res["tokens"][0]))
+
+    def _mixed_step(self, decoding: List[Sequence], prefilling: List[Sequence]) -> None:
+        """One pass over the weights: every live row decodes one token AND up to `chunk_tokens` prompt tokens of the
+        arriving sequences (oldest first) enter the cache.  A sequence whose prompt is complete gets its first token
+        from this same step."""
+        eng = self.model.engine
+        rows, toks, want, who = [], [], [], []
+        for s in decoding:
+            rows.append(s.slot); toks.append([s.last_token]); want.append(1); who.append(s)
+        budget = self.chunk_tokens
+        n_chunk_tokens = 0
+        for s in prefilling:
+            if budget <= 0:
+                break
+            n = min(len(s.prompt) - s.prefill_pos, budget)
+            last = s.prefill_pos + n == len(s.prompt)
+            rows.append(s.slot); toks.append(s.prompt[s.prefill_pos:s.prefill_pos + n]); want.append(1 if last else 0); who.append(s)
+            budget -= n
+            n_chunk_tokens += n
+        # one-token segments first (the engine's decode group): a 1-token chunk is a decode-shaped segment too
+        order = sorted(range(len(rows)), key=lambda i: 0 if len(toks[i]) == 1 else 1)
+        rows, toks, want, who = [rows[i] for i in order], [toks[i] for i in order], [want[i] for i in order], [who[i] for i in order]
+        wanted = [s for s, w in zip(who, want) if w]
+        sp = self._sample_args(wanted) if wanted else None
+        t0 = time.perf_counter()
+        ticket = eng.step_enqueue_mixed(self.kv, rows, toks, want, sp)
+        res = eng.step_wait(ticket, len(wanted))
+        dt = time.perf_counter() - t0
+        self.steps += 1
+        self.mixed_steps += 1
+        for s, tk in zip(who, toks):
+            if s in prefilling:
+                s.prefill_pos += len(tk)
+                self.chunks += 1
+        for s, t in zip(wanted, res["tokens"] if wanted else []):
+            if s in prefilling:
+                s.prefilled = True
+                self.prefills += 1
+            if not s.finished:
+                self._on_token(s, int(t))
+        if self.metrics is not None:
+            self.metrics.record_throughput({"decode_tokens": float(len(decoding)), "decode_time": dt,
+                                            "prompt_tokens": float(n_chunk_tokens), "prompt_time": dt})
 
     def _release_finished(self) -> None:
         for i, s in enumerate(self.slots):
@@ -265,6 +320,15 @@ class ContinuousScheduler:
                         drain()
                         continue
                     self.max_rows_seen = max(self.max_rows_seen, len(active))
+                    prefilling = [s for s in active if not s.prefilled]
+                    if prefilling:                           # chunked prefill rides in the live rows' decode step
+                        drain()
+                        prefilling.sort(key=lambda q: q.id)
+                        self._mixed_step([s for s in active if s.prefilled and not s.finished], prefilling)
+                        with self.cv:
+                            self._step_pending = False
+                            self.cv.notify_all()
+                        continue
                     rows = [s.slot for s in active]
                     t0 = time.perf_counter()
                     if inflight is None:

@@ -95,6 +95,34 @@ class FakeEngine:
                             "probs_row0": np.zeros(len(rows), np.float32)}
         return t
 
+    def step_enqueue_mixed(self, kv, rows, token_lists, want=None, sample=None):
+        """Segments of different lengths in one step (chunked prefill next to decode rows): per row through the oracle."""
+        rows = [int(r) for r in rows]
+        lens = [len(t) for t in token_lists]
+        if len(set(rows)) != len(rows) or sorted(lens, key=lambda n: n != 1) != lens:
+            raise ValueError("bad rows / one-token segments must come first")
+        want = [1] * len(rows) if want is None else [int(w) for w in want]
+        self.trace.append(("enqueue_mixed", tuple(rows), tuple(lens), tuple(want)))
+        c = sample.c if sample is not None else None
+        nw = sum(1 for w in want if w)
+        temps, top_ps = (getattr(sample, "_row", ([float(c.temperature)] * nw, [float(c.top_p)] * nw)) if c is not None else ([], []))
+        out, j = [], 0
+        for r, toks, w in zip(rows, token_lists, want):
+            logits = self.ref(np.asarray(toks).reshape(1, -1), cache=kv.rows[r])[:, -1]
+            if not w:
+                continue
+            u = None
+            if temps[j] != 0:
+                u = np.random.default_rng(int(c.seed) * 131 + self._next * 17 + j).random(1)
+            out.append(int(ref_sample.sample(logits, temp=float(temps[j]), top_p=float(top_ps[j]), uniforms=u)["tokens"][0, 0]))
+            j += 1
+        self._last_tokens = None
+        t = self._next
+        self._next += 1
+        self._results[t] = {"tokens": np.asarray(out, dtype=np.int32), "logprobs": np.zeros(len(out), np.float32),
+                            "probs_row0": np.zeros(len(out), np.float32)}
+        return t
+
     def forward(self, tokens, kv, all_positions=False, want_logits=True):
         lg = self.ref(np.asarray(tokens), cache=kv.caches)
         self.trace.append(("forward", np.asarray(tokens).shape))

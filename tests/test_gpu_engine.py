@@ -460,6 +460,76 @@ def test_row_subset_steps_equal_independent_sequences(tiny_dirs, name):
     eng.close()
 
 
+@pytest.mark.parametrize("kvd", ["model", "float32"])
+@pytest.mark.parametrize("name", ["llama_f32", "qwen3_bf16", "llama_q4_bf16"])
+def test_mixed_steps_chunked_prefill_next_to_decode_rows(tiny_dirs, name, kvd):
+    """mi_step_enqueue_mixed: a 70-token prompt enters the cache in chunks (32 + 32 + 6 tokens) while two live
+    sequences keep decoding IN THE SAME STEPS (one pass over the weights each); a second short prompt rides along as
+    one chunk.  Every sequence must produce what it produces alone (the oracle's single-sequence greedy run), the
+    chunked prompt's KV must equal a one-shot prefill's (next-token logits), inner chunks return nothing."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    eng = model.engine
+    exact = name == "llama_f32"
+    V = cfg["vocab_size"]
+    paged = kvd == "float32"
+    P = {"A": RNG.integers(3, V, size=9), "B": RNG.integers(3, V, size=6), "C": RNG.integers(3, V, size=70), "D": RNG.integers(3, V, size=5)}
+
+    def alone(p, n):
+        cache = ref.make_cache(1, paged=paged)
+        y, out, margins = p[None], [], []
+        for _ in range(n):
+            lg = ref(y, cache=cache)[:, -1]
+            top2 = np.sort(lg[0])[-2:]
+            margins.append(float(top2[1] - top2[0]))
+            y = np.argmax(lg, axis=-1)[:, None]
+            out.append(int(y[0, 0]))
+        return out, margins
+
+    kv = eng.new_kv(4, capacity=128, kv_dtype=kvd)
+    greedy = SampleArgs(temp=0.0)
+    got = {k: [] for k in P}
+
+    def mixed(rows, names, toks, want):
+        res = eng.step_wait(eng.step_enqueue_mixed(kv, rows, toks, want, greedy), sum(want))
+        for nm, t in zip([n for n, w in zip(names, want) if w], res["tokens"]):
+            got[nm].append(int(t))
+
+    mixed([1, 3], ["A", "B"], [P["A"], P["B"]], [1, 1])                                     # two prompts admitted in one step
+    assert kv.offsets == [0, 9, 0, 6]
+    mixed([1, 3, 0], ["A", "B", "C"], [[got["A"][-1]], [got["B"][-1]], P["C"][:32]], [1, 1, 0])     # C: first chunk, no logits
+    assert kv.offsets == [32, 10, 0, 7] and len(got["C"]) == 0
+    mixed([1, 3, 0], ["A", "B", "C"], [[got["A"][-1]], [got["B"][-1]], P["C"][32:64]], [1, 1, 0])
+    mixed([1, 3, 2, 0], ["A", "B", "D", "C"], [[got["A"][-1]], [got["B"][-1]], P["D"], P["C"][64:]], [1, 1, 1, 1])  # last chunk + D whole
+    assert kv.offsets == [70, 12, 5, 9] and len(got["C"]) == 1 and len(got["D"]) == 1
+    for _ in range(3):                                                                       # all four decode together
+        mixed([0, 1, 2, 3], ["C", "A", "D", "B"], [[got["C"][-1]], [got["A"][-1]], [got["D"][-1]], [got["B"][-1]]], [1, 1, 1, 1])
+    res = eng.step_wait(eng.step_enqueue_rows(kv, [0, 1, 2, 3], [[got["C"][-1]], [got["A"][-1]], [got["D"][-1]], [got["B"][-1]]], greedy), 4)
+    for nm, t in zip(["C", "A", "D", "B"], res["tokens"]):                                    # ... and the plain row step continues them
+        got[nm].append(int(t))
+    for nm in P:
+        want, margins = alone(P[nm], len(got[nm]))
+        for i, (g, w) in enumerate(zip(got[nm], want)):
+            if g != w:
+                assert not exact and margins[i] <= (2e-3 if paged else 0.13), (nm, i, got[nm], want, margins[i])
+                break                                              # a near-tie flip changes the continuation
+    # the chunked prompt's cache equals a one-shot prefill's: logits of the same next token, rounding noise apart
+    kv2 = eng.new_kv(1, capacity=128, kv_dtype=kvd)
+    eng.forward(P["C"][None].astype(np.int32), kv2, want_logits=False)
+    nxt = np.asarray([[got["C"][0]]], dtype=np.int32)
+    kv3 = eng.new_kv(2, capacity=128, kv_dtype=kvd)
+    eng.step_wait(eng.step_enqueue_mixed(kv3, [1], [P["C"][:40]], [0], greedy), 0)
+    eng.step_wait(eng.step_enqueue_mixed(kv3, [1], [P["C"][40:]], [1], greedy), 1)
+    a = eng.forward(nxt, kv2)
+    b = eng.forward(np.concatenate([nxt, nxt]), kv3)[1:2]
+    assert np.abs(a - b).max() <= (2e-4 if exact else (4e-3 if paged else 0.1)), np.abs(a - b).max()
+    with pytest.raises(ValueError):
+        eng.step_enqueue_mixed(kv, [0, 1], [P["C"][:8], [5]], [1, 1], greedy)              # one-token segments must come first
+    with pytest.raises(ValueError):
+        eng.step_enqueue_mixed(kv, [0, 0], [[5], [6]], [1, 1], greedy)
+    kv.close(); kv2.close(); kv3.close()
+    eng.close()
+
+
 def test_converted_checkpoint_and_lora_hot_swap(tiny_dirs, tmp_path):
     """a directory written by convert(quantize=True) loads and matches the oracle on the same
     files; weight_updater swaps adapters on the live engine (adapters.safetensors + config, then adapter.npz)."""

@@ -48,9 +48,10 @@ def _alone(tiny, ids, n, eos):
     return out, "length"
 
 
-def test_scheduler_sequences_equal_their_solo_runs_and_slots_are_recycled(tiny, parts):
+@pytest.mark.parametrize("chunk", [0, 8])
+def test_scheduler_sequences_equal_their_solo_runs_and_slots_are_recycled(tiny, parts, chunk):
     model, tok = parts
-    sched = ContinuousScheduler(model, tok, max_slots=2)
+    sched = ContinuousScheduler(model, tok, max_slots=2, chunk_tokens=chunk)
     sched.start()
     done = {}
     texts = {}
@@ -81,8 +82,18 @@ def test_scheduler_sequences_equal_their_solo_runs_and_slots_are_recycled(tiny, 
         assert done[name] == (want, reason), name
         assert "".join(texts[name]) == tok.decode(want)
     tr = model.engine.trace
-    prefills = [e for e in tr if e[0] == "enqueue_rows" and e[2] != "device-tokens" and e[2][1] > 1]
-    assert len(prefills) == 4 and all(len(e[1]) == 1 for e in prefills)       # one unpadded prefill per sequence
+    if chunk == 0:
+        prefills = [e for e in tr if e[0] == "enqueue_rows" and e[2] != "device-tokens" and e[2][1] > 1]
+        assert len(prefills) == 4 and all(len(e[1]) == 1 for e in prefills)       # one unpadded prefill per sequence
+        assert not [e for e in tr if e[0] == "enqueue_mixed"]
+    else:
+        # chunked prefill: prompts enter the cache in chunks of <= 8 tokens inside mixed steps; no prompt is prefilled alone
+        mixed = [e for e in tr if e[0] == "enqueue_mixed"]
+        assert mixed and all(sum(n for n in e[2] if n > 1) <= chunk and max(e[2]) <= chunk for e in mixed)
+        assert not [e for e in tr if e[0] == "enqueue_rows" and e[2] != "device-tokens" and e[2][1] > 1]
+        assert sum(sum(n for n, w in zip(e[2], e[3]) if not (n == 1 and w)) for e in mixed) >= sum(len(p) for p in prompts.values()) - 8
+        assert any(1 in e[2] and max(e[2]) > 1 for e in mixed)                    # a chunk rode next to a decoding row
+        assert sched.mixed_steps == len(mixed) and sched.prefills == 4 and sched.chunks >= 4
     assert any(e[0] == "enqueue_rows" and len(e[1]) == 2 for e in tr)          # two sequences share decode steps
     assert any(e[0] == "enqueue_rows" and e[2] == "device-tokens" for e in tr)  # one-step-ahead on a stable row set
     assert sum(1 for e in tr if e[0] == "reset_row") == 4 and sched.max_rows_seen == 2

@@ -3,6 +3,7 @@
 
   summarize_prof.py stats   <dir> <out.csv> "<header comment>"     (--kernel-trace --stats run)
   summarize_prof.py pmc     <dir> <COUNTER> <out.csv> "<header comment>"   (--pmc COUNTER run)
+  summarize_prof.py timeline <dir> <out.csv> "<header comment>"    (--kernel-trace run: one decode step, dispatch by dispatch)
 
 Kernel names are shortened: namespaces dropped, the template arguments of the GEMV / GEMM / attention
 kernels spelled out (dtype, weight kind, rows per call, epilogue).
@@ -107,6 +108,48 @@ def pmc(d, counter, out, header):
             o.write(f"{k},{c},{v / c:.1f}\n")
 
 
+def timeline(d, out, header, marker="sample_kernel", skip_last=70):
+    """One steady-state decode step from a --kernel-trace run: the dispatches between the last two `marker` kernels, each
+    with its start offset, duration and the idle gap in front of it (us).  Rows: the embedding, layers 0, 1 and the
+    last layer in full, the head + sampler; plus per-kernel sums over the whole step."""
+    rows = []
+    for f in find(d, "_kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), pretty(r["Kernel_Name"])))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if r[2].startswith(marker)]
+    if len(marks) < 3:
+        sys.exit("timeline: fewer than three sampler dispatches in the trace")
+    # bench.py ends with an instrumented pass (64 steps with HIP events around the dominant kernel, which open gaps of
+    # their own): take a step of the TIMED region in front of it
+    back = skip_last if len(marks) > skip_last + 2 else 1
+    a, b = marks[-back - 1] + 1, marks[-back] + 1
+    step = [r for r in rows[a:b]]
+    t0 = step[0][0]
+    span = (step[-1][1] - t0) / 1e3
+    busy = sum(e - s_ for s_, e, _ in step) / 1e3
+    agg = defaultdict(lambda: [0, 0.0])
+    for s_, e, k in step:
+        agg[k][0] += 1
+        agg[k][1] += (e - s_) / 1e3
+    with open(out, "w") as o:
+        for h in header.split("\\n"):
+            o.write(f"# {h}\n")
+        o.write(f"# one decode step: {len(step)} dispatches, {span:.1f} us from first start to last end, {busy:.1f} us inside kernels, "
+                f"{span - busy:.1f} us between them\n")
+        o.write("# per kernel over the step: " + "; ".join(f"{k} x{c} = {t:.1f} us" for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])) + "\n")
+        o.write("index,kernel,start_us,duration_us,gap_before_us\n")
+        n = len(step)
+        per_layer = max(1, (n - 4) // 32)
+        keep = set(range(0, min(n, 1 + 2 * per_layer + 1))) | set(range(max(0, n - per_layer - 4), n))
+        prev_end = None
+        for i, (s_, e, k) in enumerate(step):
+            gap = 0.0 if prev_end is None else (s_ - prev_end) / 1e3
+            prev_end = e
+            if i in keep:
+                o.write(f"{i},{k},{(s_ - t0) / 1e3:.2f},{(e - s_) / 1e3:.2f},{gap:.2f}\n")
+
+
 def rename(path):
     """Re-apply pretty() to the first column of an existing summary (merging rows that collapse)."""
     lines = open(path).read().splitlines()
@@ -125,6 +168,8 @@ if __name__ == "__main__":
             rename(f)
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
     else:
