@@ -128,6 +128,28 @@ int mi_engine_finalize(mi_engine* e);
 
 /* ---- KV cache: replaces _KVPool.get / PagedKVCache (utils.py:199-223, base.py:93-150) -- */
 int mi_kv_create(mi_engine* e, int batch, int capacity_tokens, int kv_dtype, mi_kv** out);
+/* Block-paged form for serving (the reference's continuous scheduler rebuilds its caches per batch and keeps a
+ * process-global prefix cache, server/main.py:1404-1726, utils.py:231-287): `slots` rows share an arena of `n_blocks`
+ * blocks of `block_tokens` tokens (a power of two >= 16; block 0 is reserved); a row's tokens live in the blocks its
+ * table names, so a row grows without copying, costs memory only for what it holds, and rows with a common prompt
+ * prefix can share blocks (mi_kv_prefix_*).  A row holds at most max_tokens_per_row tokens.  Every entry point that
+ * takes a mi_kv accepts either form; mi_kv_reserve is a no-op up to that limit.  MI_ERR_RUNTIME when a step needs a
+ * block and every block is held by a live sequence. */
+int mi_kv_create_paged(mi_engine* e, int slots, int block_tokens, int n_blocks, int max_tokens_per_row, int kv_dtype,
+                       mi_kv** out);
+/* Prefix reuse on a paged cache.  attach: `row` is empty; the longest run of FULL blocks at the start of tokens[0..n)
+ * that an earlier prompt has published is mapped into the row (shared, read-only), the row's length becomes
+ * *n_reused (a multiple of block_tokens, < n: at least one token is left to run) and the caller prefills
+ * tokens[*n_reused..n).  Identical tokens at identical positions give identical K / V, so this is exact up to the
+ * summation-order noise between prefill shapes; hits are verified token by token, never by hash alone.
+ * publish: the full blocks of tokens[0..n) (already in the row's cache, i.e. after its prefill was enqueued) become
+ * reusable; they stay alive after the row is reset, until evicted (least recently used first) when a step needs a
+ * block.  clear: forget everything (after a weight or adapter update).
+ * stats: out[0..n) = free blocks, usable blocks, cached blocks, reused tokens, looked-up tokens, evictions. */
+int mi_kv_prefix_attach(mi_kv* kv, int row, const int32_t* tokens, int n, int* n_reused);
+int mi_kv_prefix_publish(mi_kv* kv, int row, const int32_t* tokens, int n);
+int mi_kv_prefix_clear(mi_kv* kv);
+int mi_kv_stats(const mi_kv* kv, int64_t* out, int n);
 void mi_kv_destroy(mi_kv* kv);
 int mi_kv_reset(mi_kv* kv, int batch);               /* base.py:146-149 */
 int mi_kv_reserve(mi_kv* kv, int capacity_tokens);   /* base.py:104-117 growth, contents kept */

@@ -79,6 +79,11 @@ SIGNATURES = {
     "mi_engine_set_lora": (C.c_int, [_P, C.c_int, C.c_char_p, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int]),
     "mi_engine_finalize": (C.c_int, [_P]),
     "mi_kv_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mi_kv_create_paged": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mi_kv_prefix_attach": (C.c_int, [_P, C.c_int, _I32P, C.c_int, C.POINTER(C.c_int)]),
+    "mi_kv_prefix_publish": (C.c_int, [_P, C.c_int, _I32P, C.c_int]),
+    "mi_kv_prefix_clear": (C.c_int, [_P]),
+    "mi_kv_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int]),
     "mi_kv_destroy": (None, [_P]),
     "mi_kv_reset": (C.c_int, [_P, C.c_int]),
     "mi_kv_reserve": (C.c_int, [_P, C.c_int]),

@@ -45,7 +45,7 @@ __device__ __forceinline__ void load_row_piece(const T* p, float (&o)[N]) {
 
 // ------------------------------------------------------------------------------------------
 // rope_append: grid (Hq + 2*Hkv, B*L), block 64.  One wave per (token, head).
-template <typename AT, typename KT>
+template <typename AT, typename KT, bool PAGED>
 __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
   const AttnShape& s = c.s;
   const int head = blockIdx.x, row = blockIdx.y;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
 
   if (!is_q && !is_k) {  // values: plain append
     const int kh = head - s.Hq - s.Hkv;
-    KT* dst = (KT*)c.vcache + (((size_t)kb * s.Hkv + kh) * s.cap + pos) * D;
+    KT* dst = (KT*)c.vcache + kv_elem<PAGED>(s, kb, kh, pos);
     for (int i = lane; i < D; i += 64) dst[i] = (KT)(float)src[i];
     return;
   }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
       dst[i] = (AT)o1; dst[i + D2] = (AT)o2;
     } else {
       const int kh = head - s.Hq;
-      KT* dst = (KT*)c.kcache + (((size_t)kb * s.Hkv + kh) * s.cap + pos) * D;
+      KT* dst = (KT*)c.kcache + kv_elem<PAGED>(s, kb, kh, pos);
       // the 16-bit rounding of the model dtype happens before the (possibly wider) cache store
       dst[i] = (KT)to_f32((AT)o1); dst[i + D2] = (KT)to_f32((AT)o2);
     }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendCall c) {
 // -- the one-wave-per-(token, head) form above is 393 k tiny workgroups of 2-byte accesses at 8 x 1024 tokens
 // (104 us per layer).  Element-wise arithmetic as above; the q/k-norm sum runs over a lane's 16 elements and then over
 // the head's 8 lanes.
-template <typename AT>
+template <typename AT, bool PAGED>
 __global__ __launch_bounds__(256) void rope_append_rows_kernel(RopeAppendCall c) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void rope_append_rows_kernel(RopeAppendCall c)
     u32x4 v1 = *(const u32x4*)(src + i0), v2 = *(const u32x4*)(src + i0 + D2);
     const bool is_q = head < s.Hq, is_k = !is_q && head < s.Hq + s.Hkv;
     if (!is_q && !is_k) {                                        // values: plain append
-      AT* dst = (AT*)c.vcache + (((size_t)kb * s.Hkv + (head - s.Hq - s.Hkv)) * s.cap + pos) * D;
+      AT* dst = (AT*)c.vcache + kv_elem<PAGED>(s, kb, head - s.Hq - s.Hkv, pos);
       *(u32x4*)(dst + i0) = v1; *(u32x4*)(dst + i0 + D2) = v2;
       continue;
     }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void rope_append_rows_kernel(RopeAppendCall c)
       e2[j] = (AT)(x1 * sn[j] + x2 * cs[j]);
     }
     AT* dst = is_q ? (AT*)c.q_out + (size_t)row * nq + (size_t)head * D
-                   : (AT*)c.kcache + (((size_t)kb * s.Hkv + (head - s.Hq)) * s.cap + pos) * D;
+                   : (AT*)c.kcache + kv_elem<PAGED>(s, kb, is_q ? 0 : head - s.Hq, pos);
     *(u32x4*)(dst + i0) = v1; *(u32x4*)(dst + i0 + D2) = v2;
   }
 }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rope_append_rows_kernel(RopeAppendCall c)
 // ------------------------------------------------------------------------------------------
 // attention: grid (nsplit, B*Hkv, L), block 256 (4 waves).  Wave w, lane group gq = lane>>4
 // handles key positions s0 + 16*i + 4*w + gq; the 16 lanes of a group each own D/16 elements.
-template <typename AT, typename KT, int D, int G>
+template <typename AT, typename KT, int D, int G, bool PAGED>
 __global__ __launch_bounds__(256) void attn_kernel(AttnCall c) {
   constexpr int EPL = D / 16;
   const AttnShape& s = c.s;
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnCall c) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
   }
-  const KT* kbase = (const KT*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D + li * EPL;
-  const KT* vbase = (const KT*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D + li * EPL;
+  const KT* kbase = (const KT*)c.kcache + li * EPL;
+  const KT* vbase = (const KT*)c.vcache + li * EPL;
 
   constexpr int U = 2;
   for (int sb = s0 + 4 * wave + gq; sb < s1; sb += 16 * U) {
@@ -203,8 +203,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnCall c) {
       const int sp = sb + 16 * u;
       ok[u] = sp < s1;
       const int spc = ok[u] ? sp : s0;
-      load_row_piece<KT, EPL>(kbase + (size_t)spc * D, kk[u]);
-      load_row_piece<KT, EPL>(vbase + (size_t)spc * D, vv[u]);
+      const size_t ro = kv_elem<PAGED>(s, kb, kh, spc);
+      load_row_piece<KT, EPL>(kbase + ro, kk[u]);
+      load_row_piece<KT, EPL>(vbase + ro, vv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -301,14 +302,17 @@ int launch_attn_g(const AttnCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid(c.nsplit, s.B * s.Hkv, s.L), block(256);
   const int G = s.Hq / s.Hkv;
+#define AK(GV) do { if (s.btab) hipLaunchKernelGGL((attn_kernel<AT, KT, D, GV, true>), grid, block, 0, st, c); \
+                    else hipLaunchKernelGGL((attn_kernel<AT, KT, D, GV, false>), grid, block, 0, st, c); } while (0)
   switch (G) {
-    case 1: hipLaunchKernelGGL((attn_kernel<AT, KT, D, 1>), grid, block, 0, st, c); break;
-    case 2: hipLaunchKernelGGL((attn_kernel<AT, KT, D, 2>), grid, block, 0, st, c); break;
-    case 4: hipLaunchKernelGGL((attn_kernel<AT, KT, D, 4>), grid, block, 0, st, c); break;
-    case 5: hipLaunchKernelGGL((attn_kernel<AT, KT, D, 5>), grid, block, 0, st, c); break;
-    case 8: hipLaunchKernelGGL((attn_kernel<AT, KT, D, 8>), grid, block, 0, st, c); break;
+    case 1: AK(1); break;
+    case 2: AK(2); break;
+    case 4: AK(4); break;
+    case 5: AK(5); break;
+    case 8: AK(8); break;
     default: return fail(MI_ERR_UNSUPPORTED, "attention: Hq/Hkv must be 1, 2, 4, 5 or 8");
   }
+#undef AK
   MI_HIP(hipGetLastError());
   if (c.nsplit > 1) {
     hipLaunchKernelGGL((attn_combine_kernel<AT>), dim3(s.B * s.L * s.Hq), dim3(D), 0, st, c.partial,
@@ -337,13 +341,19 @@ int launch_rope_append(const RopeAppendCall& c, hipStream_t st) {
   if (s.D % 2 != 0) return fail(MI_ERR_UNSUPPORTED, "rope: head_dim must be even");
   if (s.D == 128 && s.rnd == RND_NONE && s.L > 1 && s.kv == s.act && (s.act == MI_BF16 || s.act == MI_F16)) {
     const dim3 grid_r(s.B * s.L), block_r(256);
-    if (s.act == MI_BF16) hipLaunchKernelGGL(rope_append_rows_kernel<bf16>, grid_r, block_r, 0, st, c);
-    else hipLaunchKernelGGL(rope_append_rows_kernel<f16>, grid_r, block_r, 0, st, c);
+    if (s.act == MI_BF16) {
+      if (s.btab) hipLaunchKernelGGL((rope_append_rows_kernel<bf16, true>), grid_r, block_r, 0, st, c);
+      else hipLaunchKernelGGL((rope_append_rows_kernel<bf16, false>), grid_r, block_r, 0, st, c);
+    } else {
+      if (s.btab) hipLaunchKernelGGL((rope_append_rows_kernel<f16, true>), grid_r, block_r, 0, st, c);
+      else hipLaunchKernelGGL((rope_append_rows_kernel<f16, false>), grid_r, block_r, 0, st, c);
+    }
     MI_HIP(hipGetLastError());
     return MI_OK;
   }
   const dim3 grid(s.Hq + 2 * s.Hkv, s.B * s.L), block(64);
-#define RA(AT, KT) hipLaunchKernelGGL((rope_append_kernel<AT, KT>), grid, block, 0, st, c)
+#define RA(AT, KT) do { if (s.btab) hipLaunchKernelGGL((rope_append_kernel<AT, KT, true>), grid, block, 0, st, c); \
+                        else hipLaunchKernelGGL((rope_append_kernel<AT, KT, false>), grid, block, 0, st, c); } while (0)
   if (s.act == MI_F32 && s.kv == MI_F32) RA(float, float);
   else if (s.act == MI_BF16 && s.kv == MI_BF16) RA(bf16, bf16);
   else if (s.act == MI_F16 && s.kv == MI_F16) RA(f16, f16);

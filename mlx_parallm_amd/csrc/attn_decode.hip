@@ -73,7 +73,7 @@ __device__ __forceinline__ void raw_to_f32(const uint32_t (&r)[NW32], float (&o)
 }
 
 // D must be a multiple of 32 for 16-bit caches (two elements per dword per lane); float caches any D % 16 == 0
-template <typename T, int D, int G, bool NORM>
+template <typename T, int D, int G, bool NORM, bool PAGED>
 __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
   constexpr int EPL = D / 16, NWV = 8, U = 8;
   constexpr int NW32 = EPL * (int)sizeof(T) / 4;
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
 
   // ---- the K/V rows of the first block go out before anything else: they depend on nothing
   // but the offsets, and their latency then hides the q / k_new prologue
-  T* kc = (T*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
-  T* vc = (T*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  T* kc = (T*)c.kcache;                          // + kv_elem(row, head, key): contiguous slabs or the block arena
+  T* vc = (T*)c.vcache;
   const int send = min(s1, pos);                 // cached keys of this split: [s0, send)
   const T* kbase = kc + li * EPL;
   const T* vbase = vc + li * EPL;
@@ -114,8 +114,9 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
       const int sp = base + 4 * wave + gq + 4 * NWV * u;
       ok[u] = sp < send;
       const int spc = ok[u] ? sp : s0;
-      load_raw<NW32>(kbase + (size_t)spc * D, kr[u]);
-      load_raw<NW32>(vbase + (size_t)spc * D, vr[u]);
+      const size_t ro = kv_elem<PAGED>(s, kb, kh, spc);
+      load_raw<NW32>(kbase + ro, kr[u]);
+      load_raw<NW32>(vbase + ro, vr[u]);
     }
   };
   if (s0 < send) issue_kv(s0);
@@ -191,10 +192,11 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
     pack(x, knr);
   }
   if (owner && wave == 0 && gq == 0 && pos < s.cap) {
+    const size_t ro = kv_elem<PAGED>(s, kb, kh, pos) + li * EPL;
 #pragma unroll
     for (int i = 0; i < NW32; ++i) {
-      ((uint32_t*)(kc + (size_t)pos * D + li * EPL))[i] = knr[i];
-      ((uint32_t*)(vc + (size_t)pos * D + li * EPL))[i] = vnr[i];
+      ((uint32_t*)(kc + ro))[i] = knr[i];
+      ((uint32_t*)(vc + ro))[i] = vnr[i];
     }
   }
 
@@ -435,7 +437,7 @@ __device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
 // and measured SLOWER than two launches -- 36.7 us with the weights prefetched from `after_loads`, 33.7 us
 // prefetched after the attention, against 19.6 + 12.1 us: the per-CU memory queue is in order, so the 128 KiB
 // of weight loads per CU sit in front of every dependent load of the attention's latency chain.  Dropped.
-template <typename T, int D, int G, bool NORM, bool WT, class Hook>
+template <typename T, int D, int G, bool NORM, bool WT, bool PAGED, class Hook>
 __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, unsigned char* smem, Hook after_loads) {
   constexpr bool F32 = sizeof(T) == 4;
   static_assert(D % 32 == 0 && D <= 128 && G <= 8 && (!F32 || D % 64 == 0), "16-bit caches: head_dim 32/64/96/128; float32: 64/128");
@@ -470,8 +472,8 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   float* st_l = st_m + 9 * G;
   int& is_last_sh = *(int*)(st_l + 9 * G);       // (no static __shared__ in front of the dynamic region)
 
-  T* kc = (T*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
-  T* vc = (T*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  T* kc = (T*)c.kcache;                          // + kv_elem(row, head, key): contiguous slabs or the block arena
+  T* vc = (T*)c.vcache;
   const int send = min(s0 + chunk, pos);         // cached keys of this split: [s0, send)
 
   // ---- the K fragments and V rows of the first round go out before anything else
@@ -482,14 +484,16 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     const int k0 = base + KPW * wave;
     if constexpr (F32) {
       const int key = min(k0 + c16, klast);
+      const size_t ro = kv_elem<PAGED>(s, kb, kh, key);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) kf32[i] = *(const f32x4*)(kc + (size_t)key * D + 16 * i + 4 * g4);
+      for (int i = 0; i < NP; ++i) kf32[i] = *(const f32x4*)(kc + ro + 16 * i + 4 * g4);
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int key = min(k0 + 16 * t + c16, klast);
+        const size_t ro = kv_elem<PAGED>(s, kb, kh, key);
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[t][kk] = *(const u32x4*)(kc + (size_t)key * D + 32 * kk + 8 * g4);
+        for (int kk = 0; kk < KK; ++kk) kf[t][kk] = *(const u32x4*)(kc + ro + 32 * kk + 8 * g4);
       }
     }
   };
@@ -499,15 +503,16 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = min(k0 + 4 * g4 + r, klast);
+        const size_t ro = kv_elem<PAGED>(s, kb, kh, key);
 #pragma unroll
-        for (int h = 0; h < NH; ++h) vv32[r][h] = *(const f32x4*)(vc + (size_t)key * D + 64 * h + 4 * c16);
+        for (int h = 0; h < NH; ++h) vv32[r][h] = *(const f32x4*)(vc + ro + 64 * h + 4 * c16);
       }
     } else {                                     // 32 keys x (D/8) 16-byte pieces, lane-linear: piece = i * 64 + lane
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int piece = i * 64 + lane, kl = piece / (D / 8), dc = piece % (D / 8);
         const int key = min(k0 + kl, klast);
-        vrow[i] = *(const u32x4*)(vc + (size_t)key * D + 8 * dc);
+        vrow[i] = *(const u32x4*)(vc + kv_elem<PAGED>(s, kb, kh, key) + 8 * dc);
       }
     }
   };
@@ -570,7 +575,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     for (int i = 0; i < NW32; ++i) ((uint32_t*)(q_sh + (size_t)vi * D + li * EPL))[i] = pk[i];
   }
   if (owner && (is_k || is_v) && pos < s.cap) {  // KV append (base.py:66-85)
-    T* dst = (is_k ? kc : vc) + (size_t)pos * D + li * EPL;
+    T* dst = (is_k ? kc : vc) + kv_elem<PAGED>(s, kb, kh, pos) + li * EPL;
 #pragma unroll
     for (int i = 0; i < NW32; ++i) ((uint32_t*)dst)[i] = pk[i];
   }
@@ -796,20 +801,26 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   }
 }
 
-template <typename T, int D, int G, bool NORM>
+template <typename T, int D, int G, bool NORM, bool PAGED>
 __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  attn_decode_mfma_body<T, D, G, NORM, false>(c, smem, NoHook{});
+  attn_decode_mfma_body<T, D, G, NORM, false, PAGED>(c, smem, NoHook{});
 }
 
 template <typename T, int D, int G, bool NORM>
 int launch_mfma_g(const AttnDecodeCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
-  auto kern = attn_decode_mfma_kernel<T, D, G, NORM>;
   constexpr size_t lds = attn_mfma_lds_bytes<G, D, (int)sizeof(T)>();
-  MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, grid, block, lds, st, c);
+  if (s.btab) {
+    auto kern = attn_decode_mfma_kernel<T, D, G, NORM, true>;
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, c);
+  } else {
+    auto kern = attn_decode_mfma_kernel<T, D, G, NORM, false>;
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, c);
+  }
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -838,14 +849,17 @@ int launch_gn(const AttnDecodeCall& c, hipStream_t st) {
     if (c.variant != 1) return launch_mfma_gn<T, D, NORM>(c, st);
   }
   const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
+#define DK(GV) do { if (s.btab) hipLaunchKernelGGL((attn_decode_kernel<T, D, GV, NORM, true>), grid, block, 0, st, c); \
+                    else hipLaunchKernelGGL((attn_decode_kernel<T, D, GV, NORM, false>), grid, block, 0, st, c); } while (0)
   switch (s.Hq / s.Hkv) {
-    case 1: hipLaunchKernelGGL((attn_decode_kernel<T, D, 1, NORM>), grid, block, 0, st, c); break;
-    case 2: hipLaunchKernelGGL((attn_decode_kernel<T, D, 2, NORM>), grid, block, 0, st, c); break;
-    case 4: hipLaunchKernelGGL((attn_decode_kernel<T, D, 4, NORM>), grid, block, 0, st, c); break;
-    case 5: hipLaunchKernelGGL((attn_decode_kernel<T, D, 5, NORM>), grid, block, 0, st, c); break;
-    case 8: hipLaunchKernelGGL((attn_decode_kernel<T, D, 8, NORM>), grid, block, 0, st, c); break;
+    case 1: DK(1); break;
+    case 2: DK(2); break;
+    case 4: DK(4); break;
+    case 5: DK(5); break;
+    case 8: DK(8); break;
     default: return fail(MI_ERR_UNSUPPORTED, "attention: Hq/Hkv must be 1, 2, 4, 5 or 8");
   }
+#undef DK
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 constexpr int QT = 16;      // queries per workgroup
 constexpr int KB = 32;      // keys per block
 
-template <typename T, int D, int G>
+template <typename T, int D, int G, bool PAGED>
 __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
   static_assert(sizeof(T) == 2 && D % 32 == 0 && D <= 128, "16-bit activations / caches, head_dim 32..128");
   constexpr int KK = D / 32, DT = D / 16, NT = G * 64;
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
   __shared__ __attribute__((aligned(16))) unsigned char kimg[2][IMG];
   __shared__ __attribute__((aligned(16))) unsigned char vimg[2][IMG];
 
-  const T* kc = (const T*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
-  const T* vc = (const T*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  const T* kc = (const T*)c.kcache;
+  const T* vc = (const T*)c.vcache;
 
   u32x4 kreg[NP], vreg[NP];
   auto load_block = [&](int j) {
@@ -79,8 +79,9 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
     for (int i = 0; i < NP; ++i) {
       const int piece = min(i * NT + tid, NPIECE - 1);
       const int key = min(j * KB + piece / (D / 8), nk - 1), dc = piece % (D / 8);
-      kreg[i] = *(const u32x4*)(kc + (size_t)key * D + 8 * dc);
-      vreg[i] = *(const u32x4*)(vc + (size_t)key * D + 8 * dc);
+      const size_t ro = kv_elem<PAGED>(s, kb, kh, key) + 8 * dc;
+      kreg[i] = *(const u32x4*)(kc + ro);
+      vreg[i] = *(const u32x4*)(vc + ro);
     }
   };
   auto store_block = [&](int buf) {
@@ -183,7 +184,8 @@ template <typename T, int D, int G>
 int launch_pg(const AttnCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid((s.L + QT - 1) / QT, s.B * s.Hkv), block(G * 64);
-  hipLaunchKernelGGL((attn_prefill_kernel<T, D, G>), grid, block, 0, st, c);
+  if (s.btab) hipLaunchKernelGGL((attn_prefill_kernel<T, D, G, true>), grid, block, 0, st, c);
+  else hipLaunchKernelGGL((attn_prefill_kernel<T, D, G, false>), grid, block, 0, st, c);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -224,7 +226,7 @@ int launch_pt(const AttnCall& c, hipStream_t st) {
 //     same labelling for the decode step).
 constexpr int KB32 = 16;    // keys per block, float32 kernel
 
-template <int D, int G>
+template <int D, int G, bool PAGED>
 __global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
   static_assert(D % 64 == 0 && D <= 128, "float32: head_dim 64 / 128");
   constexpr int NP = D / 16, NH = D / 64, DT = D / 16, NT = G * 64;
@@ -248,8 +250,8 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
   __shared__ __attribute__((aligned(16))) unsigned char kimg[2][IMG];
   __shared__ __attribute__((aligned(16))) unsigned char vimg[2][IMG];
 
-  const float* kc = (const float*)c.kcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
-  const float* vc = (const float*)c.vcache + ((size_t)kb * s.Hkv + kh) * s.cap * D;
+  const float* kc = (const float*)c.kcache;
+  const float* vc = (const float*)c.vcache;
 
   f32x4 kreg[NLD], vreg[NLD];
   auto load_block = [&](int j) {
@@ -257,8 +259,9 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
     for (int i = 0; i < NLD; ++i) {
       const int piece = min(i * NT + tid, NPIECE - 1);
       const int key = min(j * KB32 + piece / (D / 4), nk - 1), dc = piece % (D / 4);
-      kreg[i] = *(const f32x4*)(kc + (size_t)key * D + 4 * dc);
-      vreg[i] = *(const f32x4*)(vc + (size_t)key * D + 4 * dc);
+      const size_t ro = kv_elem<PAGED>(s, kb, kh, key) + 4 * dc;
+      kreg[i] = *(const f32x4*)(kc + ro);
+      vreg[i] = *(const f32x4*)(vc + ro);
     }
   };
   auto store_block = [&](int buf) {
@@ -350,7 +353,8 @@ template <int D, int G>
 int launch_pg32(const AttnCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid((s.L + QT - 1) / QT, s.B * s.Hkv), block(G * 64);
-  hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G>), grid, block, 0, st, c);
+  if (s.btab) hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G, true>), grid, block, 0, st, c);
+  else hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G, false>), grid, block, 0, st, c);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

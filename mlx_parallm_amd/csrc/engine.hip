@@ -8,8 +8,10 @@
 // step needs no host data at all.
 #include <algorithm>
 #include <cstring>
+#include <list>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
@@ -132,6 +134,23 @@ struct mi_kv {
   int32_t* d_rows = nullptr;     // [B] scratch: cache rows of the current call (continuous batching)
   float* partial = nullptr; int partial_splits = 0;
   int* counters = nullptr;       // [B*Hkv] split-arrival tickets of the fused decode attention
+  // ---- block-paged form (mi_kv_create_paged): k / v are arenas [layer][block][Hkv][1 << bs_shift][D]; a row owns the
+  // blocks its table names, in order; block 0 is never handed out (unassigned table entries point at it, so a clamped
+  // address is always mapped memory); cap = bt_stride << bs_shift is the longest sequence a row can hold
+  bool paged = false;
+  int bs_shift = 0, nblocks = 0, bt_stride = 0;
+  int32_t* d_btab = nullptr;
+  std::vector<int32_t> h_btab;   // [B][bt_stride]
+  std::vector<int> row_blocks;   // blocks in use per row
+  std::vector<int> refcnt;       // per block: rows that map it + 1 if the prefix cache holds it
+  std::vector<int> free_blocks;
+  bool btab_dirty = false;
+  // prefix cache: full blocks of prompts, keyed by the hash of ALL tokens up to and including the block; an entry keeps
+  // the block's own tokens and its parent's key, so a hit is verified token by token (no reliance on the hash alone)
+  struct PrefixEntry { int block; uint64_t parent; std::vector<int32_t> tokens; std::list<uint64_t>::iterator lru_it; };
+  std::unordered_map<uint64_t, PrefixEntry> prefix;
+  std::list<uint64_t> lru;       // front = most recently used
+  int64_t stat_hit_tokens = 0, stat_lookup_tokens = 0, stat_evictions = 0;
 };
 
 namespace {
@@ -503,6 +522,86 @@ int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear
   return MI_OK;
 }
 
+
+// ---- block-paged KV: host-side block management (the device only sees the table) ------------------------------------
+uint64_t prefix_hash(uint64_t parent, const int32_t* toks, int n) {
+  uint64_t h = parent ^ 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < n; ++i) { h ^= (uint64_t)(uint32_t)toks[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xD6E8FEB86659FD93ull; }
+  return h ? h : 1;
+}
+
+void kv_release_block(mi_kv* kv, int blk) {
+  if (blk <= 0) return;
+  if (--kv->refcnt[blk] == 0) kv->free_blocks.push_back(blk);
+}
+
+// a block nobody but the prefix cache holds can be taken back (least recently used first)
+bool kv_evict_one(mi_kv* kv) {
+  for (auto it = kv->lru.rbegin(); it != kv->lru.rend(); ++it) {
+    auto pe = kv->prefix.find(*it);
+    if (pe == kv->prefix.end()) continue;
+    if (kv->refcnt[pe->second.block] == 1) {
+      const int blk = pe->second.block;
+      kv->lru.erase(pe->second.lru_it);
+      kv->prefix.erase(pe);
+      kv_release_block(kv, blk);
+      ++kv->stat_evictions;
+      return true;
+    }
+  }
+  return false;
+}
+
+int kv_take_block(mi_kv* kv) {
+  if (kv->free_blocks.empty() && !kv_evict_one(kv)) return -1;
+  const int blk = kv->free_blocks.back();
+  kv->free_blocks.pop_back();
+  kv->refcnt[blk] = 1;
+  return blk;
+}
+
+// the row's table covers `tokens` positions after this
+int kv_ensure_blocks(mi_kv* kv, int row, int tokens) {
+  if (!kv->paged) return MI_OK;
+  const int need = (tokens + (1 << kv->bs_shift) - 1) >> kv->bs_shift;
+  if (need > kv->bt_stride) return fail(MI_ERR_INVALID, "paged KV: sequence longer than the row's block table");
+  while (kv->row_blocks[row] < need) {
+    const int blk = kv_take_block(kv);
+    if (blk < 0) return fail(MI_ERR_RUNTIME, "paged KV: the block arena is exhausted (every block is held by a live sequence)");
+    kv->h_btab[(size_t)row * kv->bt_stride + kv->row_blocks[row]++] = blk;
+    kv->btab_dirty = true;
+  }
+  return MI_OK;
+}
+
+void kv_release_row(mi_kv* kv, int row) {
+  if (!kv->paged) return;
+  for (int i = 0; i < kv->row_blocks[row]; ++i) {
+    kv_release_block(kv, kv->h_btab[(size_t)row * kv->bt_stride + i]);
+    kv->h_btab[(size_t)row * kv->bt_stride + i] = 0;
+  }
+  if (kv->row_blocks[row] > 0) kv->btab_dirty = true;
+  kv->row_blocks[row] = 0;
+}
+
+int kv_upload_table(mi_kv* kv, hipStream_t st) {
+  if (kv->paged && kv->btab_dirty) {
+    // (pageable host memory: the copy is staged by the runtime before the call returns, so h_btab may change afterwards)
+    MI_HIP(hipMemcpyAsync(kv->d_btab, kv->h_btab.data(), kv->h_btab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    kv->btab_dirty = false;
+  }
+  return MI_OK;
+}
+
+void kv_shape(const mi_kv* kv, AttnShape& s) {
+  if (kv->paged) { s.btab = kv->d_btab; s.bt_stride = kv->bt_stride; s.bs_shift = kv->bs_shift; }
+}
+
+size_t kv_layer_elems(const mi_kv* kv, const mi_model_desc& d) {
+  return kv->paged ? ((size_t)kv->nblocks * d.num_kv_heads << kv->bs_shift) * d.head_dim
+                   : (size_t)kv->B * d.num_kv_heads * kv->cap * d.head_dim;
+}
+
 int choose_nsplit(const mi_kv* kv, int B, int Hkv, int L, const int32_t* rows = nullptr) {
   if (L != 1) return 1;
   int mx = 0;
@@ -542,12 +641,14 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     MI_HIP(hipMemcpyAsync(kv->d_rows, rows, B * sizeof(int32_t), hipMemcpyHostToDevice, st));
     d_rows = kv->d_rows;
   }
+  for (int b = 0; b < B; ++b) MI_TRY(kv_ensure_blocks(kv, row_of(b), kv->h_off[row_of(b)] + L));
+  MI_TRY(kv_upload_table(kv, st));
 
   { Prof pr(e, "embed");
     EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
     MI_TRY(launch_embed(e->embed.W, ec, st)); }
 
-  const size_t layer_elems = (size_t)kv->B * Hkv * kv->cap * D;
+  const size_t layer_elems = kv_layer_elems(kv, d);
   const size_t kes = dtype_size(kv->dtype);
   const int nsplit = choose_nsplit(kv, B, Hkv, L, rows);
   if (nsplit > 1) {
@@ -582,6 +683,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
     if (!qkv_done) MI_TRY(gemv_rows(e, lw.qkv, qkv_call(li), R, es, es, "gemv_qkv"));
     qkv_done = false;
     AttnShape s{B, L, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, d_rows};
+    kv_shape(kv, s);
     void* kc = (char*)kv->k + (size_t)li * layer_elems * kes;
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
     // o_proj + residual (llama.py:143,188)
@@ -673,12 +775,14 @@ int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* l
   e->sq_valid = false;
   if (!kv->d_rows) MI_HIP(hipMalloc(&kv->d_rows, kv->B * sizeof(int32_t)));
   MI_HIP(hipMemcpyAsync(kv->d_rows, rows, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  for (int i = 0; i < n; ++i) MI_TRY(kv_ensure_blocks(kv, rows[i], kv->h_off[rows[i]] + lens[i]));
+  MI_TRY(kv_upload_table(kv, st));
 
   { Prof pr(e, "embed");
     EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
     MI_TRY(launch_embed(e->embed.W, ec, st)); }
 
-  const size_t layer_elems = (size_t)kv->B * Hkv * kv->cap * D;
+  const size_t layer_elems = kv_layer_elems(kv, d);
   const size_t kes = dtype_size(kv->dtype);
   const int nsplit = nd > 0 ? choose_nsplit(kv, nd, Hkv, 1, rows) : 1;
   if (nsplit > 1 && (kv->partial == nullptr || kv->partial_splits < nsplit)) {
@@ -701,6 +805,7 @@ int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* l
     void* vc = (char*)kv->v + (size_t)li * layer_elems * kes;
     if (nd > 0) {                                // the decode rows: tokens [0, nd)
       AttnShape s{nd, 1, Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, kv->d_rows};
+      kv_shape(kv, s);
       if (e->opt_fused_attn && attention_decode_supported(s)) {
         AttnDecodeCall ac{s, e->qkv, kc, vc, kv->d_off, q_norm, k_norm, d.rms_norm_eps, e->cos_tab, e->sin_tab,
                           e->attn, 1.0f / sqrtf((float)D), RND_NONE, nsplit, kv->partial, kv->counters,
@@ -721,6 +826,7 @@ int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* l
     }
     for (int i = nd; i < n; ++i) {               // every chunk: rope + append + causal attention on its own row
       AttnShape s{1, lens[i], Hq, Hkv, D, act, kv->dtype, rnd, kv->cap, kv->d_rows + i};
+      kv_shape(kv, s);
       const void* qkv_i = (const char*)e->qkv + tok0[i] * (size_t)nqkv * es;
       void* q_i = (char*)e->q + tok0[i] * (size_t)Hq * D * es;
       void* o_i = (char*)e->attn + tok0[i] * (size_t)Hq * D * es;
@@ -1042,11 +1148,127 @@ int mi_kv_create(mi_engine* e, int batch, int capacity_tokens, int kv_dtype, mi_
   return MI_OK;
 }
 
+int mi_kv_create_paged(mi_engine* e, int slots, int block_tokens, int n_blocks, int max_tokens_per_row, int kv_dtype, mi_kv** out) {
+  if (!e || !out) return fail(MI_ERR_INVALID, "null argument");
+  if (slots < 1 || n_blocks < 2 || max_tokens_per_row < 1) return fail(MI_ERR_INVALID, "slots, blocks and tokens per row must be positive (block 0 is reserved)");
+  if (block_tokens < 16 || (block_tokens & (block_tokens - 1)) != 0) return fail(MI_ERR_INVALID, "block_tokens must be a power of two >= 16");
+  if (max_tokens_per_row > e->d.max_positions) return fail(MI_ERR_INVALID, "max_tokens_per_row exceeds desc.max_positions");
+  MI_HIP(hipSetDevice(e->device));
+  mi_kv* kv = new mi_kv();
+  kv->e = e; kv->B = slots; kv->paged = true;
+  while ((1 << kv->bs_shift) < block_tokens) ++kv->bs_shift;
+  kv->nblocks = n_blocks;
+  kv->bt_stride = (max_tokens_per_row + block_tokens - 1) / block_tokens;
+  kv->cap = std::min(kv->bt_stride * block_tokens, e->d.max_positions);
+  if (kv_dtype == MI_KV_MODEL || kv_dtype == e->d.act_dtype) { kv->dtype = e->d.act_dtype; kv->quirk = false; }
+  else if (kv_dtype == MI_F32) { kv->dtype = MI_F32; kv->quirk = true; }
+  else { delete kv; return fail(MI_ERR_UNSUPPORTED, "kv dtype must be the model dtype or float32"); }
+  const size_t bytes = (size_t)e->d.num_layers * n_blocks * e->d.num_kv_heads * block_tokens * e->d.head_dim * dtype_size(kv->dtype);
+  const size_t nctr = (size_t)slots * e->d.num_kv_heads;
+  const size_t ntab = (size_t)slots * kv->bt_stride;
+  if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess ||
+      hipMalloc(&kv->d_off, slots * sizeof(int32_t)) != hipSuccess || hipMalloc(&kv->counters, nctr * sizeof(int)) != hipSuccess ||
+      hipMalloc(&kv->d_btab, ntab * sizeof(int32_t)) != hipSuccess) {
+    hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->counters); hipFree(kv->d_btab); delete kv;
+    return fail(MI_ERR_RUNTIME, "out of device memory allocating the paged KV arena");
+  }
+  MI_HIP(hipMemsetAsync(kv->counters, 0, nctr * sizeof(int), e->stream));
+  MI_HIP(hipMemsetAsync(kv->k, 0, bytes, e->stream));
+  MI_HIP(hipMemsetAsync(kv->v, 0, bytes, e->stream));
+  MI_HIP(hipMemsetAsync(kv->d_off, 0, slots * sizeof(int32_t), e->stream));
+  MI_HIP(hipMemsetAsync(kv->d_btab, 0, ntab * sizeof(int32_t), e->stream));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  kv->h_off.assign(slots, 0);
+  kv->h_btab.assign(ntab, 0);
+  kv->row_blocks.assign(slots, 0);
+  kv->refcnt.assign(n_blocks, 0);
+  for (int b = n_blocks - 1; b >= 1; --b) kv->free_blocks.push_back(b);     // block 0 stays out of circulation
+  *out = kv;
+  return MI_OK;
+}
+
+int mi_kv_prefix_attach(mi_kv* kv, int row, const int32_t* tokens, int n, int* n_reused) {
+  if (!kv || !tokens || !n_reused) return fail(MI_ERR_INVALID, "null argument");
+  if (!kv->paged) return fail(MI_ERR_INVALID, "prefix reuse needs a paged KV (mi_kv_create_paged)");
+  if (row < 0 || row >= kv->B) return fail(MI_ERR_INVALID, "row out of range");
+  if (kv->h_off[row] != 0 || kv->row_blocks[row] != 0) return fail(MI_ERR_INVALID, "prefix attach: the row must be empty (mi_kv_reset_row first)");
+  const int bs = 1 << kv->bs_shift;
+  uint64_t parent = 0;
+  int reused = 0;
+  // full blocks only, and at least one token of the prompt is left to run (its logits are needed)
+  while (reused + bs <= n - 1 && kv->row_blocks[row] < kv->bt_stride) {
+    const uint64_t h = prefix_hash(parent, tokens + reused, bs);
+    auto it = kv->prefix.find(h);
+    if (it == kv->prefix.end() || it->second.parent != parent ||
+        memcmp(it->second.tokens.data(), tokens + reused, bs * sizeof(int32_t)) != 0) break;
+    kv->h_btab[(size_t)row * kv->bt_stride + kv->row_blocks[row]++] = it->second.block;
+    ++kv->refcnt[it->second.block];
+    kv->lru.erase(it->second.lru_it);
+    kv->lru.push_front(h);
+    it->second.lru_it = kv->lru.begin();
+    parent = h;
+    reused += bs;
+  }
+  kv->stat_lookup_tokens += n;
+  kv->stat_hit_tokens += reused;
+  if (reused > 0) {
+    kv->btab_dirty = true;
+    kv->h_off[row] = reused;
+    MI_HIP(hipSetDevice(kv->e->device));
+    MI_HIP(hipMemsetD32Async((hipDeviceptr_t)(kv->d_off + row), reused, 1, kv->e->stream));
+  }
+  *n_reused = reused;
+  return MI_OK;
+}
+
+int mi_kv_prefix_publish(mi_kv* kv, int row, const int32_t* tokens, int n) {
+  if (!kv || !tokens) return fail(MI_ERR_INVALID, "null argument");
+  if (!kv->paged) return fail(MI_ERR_INVALID, "prefix reuse needs a paged KV (mi_kv_create_paged)");
+  if (row < 0 || row >= kv->B) return fail(MI_ERR_INVALID, "row out of range");
+  if (n > kv->h_off[row]) return fail(MI_ERR_INVALID, "prefix publish: those tokens are not in the row's cache yet");
+  const int bs = 1 << kv->bs_shift;
+  uint64_t parent = 0;
+  for (int i = 0; (i + 1) * bs <= n; ++i) {
+    const uint64_t h = prefix_hash(parent, tokens + i * bs, bs);
+    auto it = kv->prefix.find(h);
+    if (it == kv->prefix.end()) {
+      const int blk = kv->h_btab[(size_t)row * kv->bt_stride + i];
+      mi_kv::PrefixEntry pe;
+      pe.block = blk; pe.parent = parent; pe.tokens.assign(tokens + i * bs, tokens + (i + 1) * bs);
+      kv->lru.push_front(h);
+      pe.lru_it = kv->lru.begin();
+      kv->prefix.emplace(h, std::move(pe));
+      ++kv->refcnt[blk];                      // the cache's own reference: the block outlives the row
+    } else if (it->second.parent != parent || memcmp(it->second.tokens.data(), tokens + i * bs, bs * sizeof(int32_t)) != 0) {
+      break;                                  // a different prefix owns this key: leave it (and everything behind it) alone
+    }
+    parent = h;
+  }
+  return MI_OK;
+}
+
+int mi_kv_prefix_clear(mi_kv* kv) {
+  if (!kv) return fail(MI_ERR_INVALID, "null kv");
+  for (auto& p : kv->prefix) kv_release_block(kv, p.second.block);
+  kv->prefix.clear();
+  kv->lru.clear();
+  return MI_OK;
+}
+
+int mi_kv_stats(const mi_kv* kv, int64_t* out, int n) {
+  if (!kv || !out) return fail(MI_ERR_INVALID, "null argument");
+  const int64_t v[6] = {kv->paged ? (int64_t)kv->free_blocks.size() : -1, kv->paged ? (int64_t)kv->nblocks - 1 : -1,
+                        (int64_t)kv->prefix.size(), kv->stat_hit_tokens, kv->stat_lookup_tokens, kv->stat_evictions};
+  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+  return MI_OK;
+}
+
 void mi_kv_destroy(mi_kv* kv) {
   if (!kv) return;
   hipSetDevice(kv->e->device);
   hipStreamSynchronize(kv->e->stream);
   hipFree(kv->k); hipFree(kv->v); hipFree(kv->d_off); hipFree(kv->partial); hipFree(kv->counters); hipFree(kv->d_rows);
+  hipFree(kv->d_btab);
   delete kv;
 }
 
@@ -1057,6 +1279,7 @@ int mi_kv_reset(mi_kv* kv, int batch) {
   MI_HIP(hipMemsetAsync(kv->d_off, 0, kv->B * sizeof(int32_t), kv->e->stream));
   MI_HIP(hipStreamSynchronize(kv->e->stream));
   std::fill(kv->h_off.begin(), kv->h_off.end(), 0);
+  for (int r = 0; r < kv->B; ++r) kv_release_row(kv, r);
   return MI_OK;
 }
 
@@ -1066,6 +1289,7 @@ int mi_kv_reset_row(mi_kv* kv, int row) {
   MI_HIP(hipSetDevice(kv->e->device));
   MI_HIP(hipMemsetAsync(kv->d_off + row, 0, sizeof(int32_t), kv->e->stream));   // ordered behind the steps already enqueued
   kv->h_off[row] = 0;
+  kv_release_row(kv, row);      // (paged: the blocks go back to the pool; whoever gets them next writes behind the steps in flight)
   return MI_OK;
 }
 
@@ -1073,6 +1297,7 @@ int mi_kv_reserve(mi_kv* kv, int capacity_tokens) {
   if (!kv) return fail(MI_ERR_INVALID, "null kv");
   if (capacity_tokens <= kv->cap) return MI_OK;
   mi_engine* e = kv->e;
+  if (kv->paged) return fail(MI_ERR_INVALID, "paged KV: a row holds at most block_tokens x table length tokens (create a larger table)");
   if (capacity_tokens > e->d.max_positions) return fail(MI_ERR_INVALID, "capacity exceeds desc.max_positions");
   MI_HIP(hipSetDevice(e->device));
   const size_t es = dtype_size(kv->dtype);

@@ -146,7 +146,23 @@ struct AttnShape {
   int cap;      // cache capacity (tokens)
   const int32_t* rows;  // device [B] or null: batch entry b lives in cache row rows[b] (continuous batching:
                         // the call covers a subset of the cache's rows); offsets[] is indexed by cache row
+  // Block-paged cache (mi_kv_create_paged): the cache arrays are arenas [block][Hkv][1 << bs_shift][D] and token `key` of
+  // cache row r lives in block btab[r * bt_stride + (key >> bs_shift)].  btab == null: contiguous [row][Hkv][cap][D].
+  const int32_t* btab;
+  int bt_stride;
+  int bs_shift;
 };
+
+// element index of (cache row kb, kv head kh, token key, d = 0) in a K or V array
+template <bool PAGED>
+__device__ __forceinline__ size_t kv_elem(const AttnShape& s, int kb, int kh, int key) {
+  if constexpr (PAGED) {
+    const int blk = s.btab[(size_t)kb * s.bt_stride + (key >> s.bs_shift)];
+    return ((((size_t)blk * s.Hkv + kh) << s.bs_shift) + (size_t)(key & ((1 << s.bs_shift) - 1))) * s.D;
+  } else {
+    return (((size_t)kb * s.Hkv + kh) * s.cap + key) * s.D;
+  }
+}
 struct RopeAppendCall {
   AttnShape s;
   const void* qkv;       // [B*L][(Hq+2Hkv)*D]

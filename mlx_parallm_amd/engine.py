@@ -153,6 +153,51 @@ class KVCache:
             pass
 
 
+class PagedKVCache(KVCache):
+    """Block-paged KV handle (``mi_kv_create_paged``): ``slots`` rows over an arena of ``n_blocks`` blocks of
+    ``block_tokens`` tokens; rows grow without copies and can share the full blocks of a common prompt prefix."""
+
+    def __init__(self, engine: "Engine", slots: int, block_tokens: int = 64, n_blocks: Optional[int] = None,
+                 max_tokens_per_row: Optional[int] = None, kv_dtype: str = "model"):
+        self.engine = engine
+        self.batch_size = int(slots)
+        self.step = int(block_tokens)
+        self.kv_dtype = kv_dtype
+        self.block_tokens = int(block_tokens)
+        max_row = int(max_tokens_per_row or engine.max_positions)
+        if n_blocks is None:                       # enough for every row at full length, + the reserved block 0
+            n_blocks = self.batch_size * ((max_row + self.block_tokens - 1) // self.block_tokens) + 1
+        code = L.MI_KV_MODEL if kv_dtype == "model" else _DT_NAMES[kv_dtype]
+        self._h = C.c_void_p()
+        L.check(L.lib().mi_kv_create_paged(engine._h, self.batch_size, self.block_tokens, int(n_blocks), max_row, code,
+                                           C.byref(self._h)))
+        engine._kvs.add(self)
+
+    def ensure(self, needed_tokens: int) -> None:
+        if needed_tokens > self.capacity:
+            raise ValueError(f"context of {needed_tokens} tokens exceeds the row limit of this paged cache ({self.capacity})")
+
+    def prefix_attach(self, row: int, tokens) -> int:
+        """Map the published full blocks of this prompt's prefix into the (empty) row; -> tokens already in the cache."""
+        t = _i32(tokens).reshape(-1)
+        n = C.c_int(0)
+        L.check(L.lib().mi_kv_prefix_attach(self._h, int(row), t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), C.byref(n)))
+        return int(n.value)
+
+    def prefix_publish(self, row: int, tokens) -> None:
+        t = _i32(tokens).reshape(-1)
+        L.check(L.lib().mi_kv_prefix_publish(self._h, int(row), t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)))
+
+    def prefix_clear(self) -> None:
+        L.check(L.lib().mi_kv_prefix_clear(self._h))
+
+    def stats(self) -> Dict[str, int]:
+        out = (C.c_int64 * 6)()
+        L.check(L.lib().mi_kv_stats(self._h, out, 6))
+        keys = ("free_blocks", "usable_blocks", "cached_blocks", "reused_tokens", "lookup_tokens", "evictions")
+        return {k: int(v) for k, v in zip(keys, out)}
+
+
 class Engine:
     """One model replica on one MI355X (``mi_engine``)."""
 
@@ -239,6 +284,14 @@ class Engine:
             torch.cuda.synchronize()
         L.check(L.lib().mi_engine_set_lora(self._h, int(layer), proj.encode(), C.c_void_p(ta.data_ptr()),
                                            C.c_void_p(tb.data_ptr()), rank, float(scale), L.MI_F32, int(ta.is_cuda)))
+        self.invalidate_prefix_caches()
+
+    def invalidate_prefix_caches(self) -> None:
+        """K / V computed with other weights must not be reused: forget the published prefixes of every paged cache
+        of this engine (called by set_lora, i.e. by load_adapters and the LoRA hot-swap of weight_updater.py)."""
+        for kv in list(self._kvs):
+            if isinstance(kv, PagedKVCache) and kv._h:
+                kv.prefix_clear()
 
     def finalize(self) -> None:
         L.check(L.lib().mi_engine_finalize(self._h))
@@ -247,6 +300,10 @@ class Engine:
     # -- hot path
     def new_kv(self, batch_size: int, capacity: int = 256, kv_dtype: str = "float32", step: int = 256) -> KVCache:
         return KVCache(self, batch_size, capacity, kv_dtype, step)
+
+    def new_paged_kv(self, slots: int, block_tokens: int = 64, n_blocks: Optional[int] = None,
+                     max_tokens_per_row: Optional[int] = None, kv_dtype: str = "model") -> PagedKVCache:
+        return PagedKVCache(self, slots, block_tokens, n_blocks, max_tokens_per_row, kv_dtype)
 
     def forward(self, tokens, kv: KVCache, all_positions: bool = False, want_logits: bool = True):
         """``model(y, cache=cache)`` (utils.py:403): tokens (B, L) -> float32 logits

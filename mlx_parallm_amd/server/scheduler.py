@@ -64,14 +64,25 @@ class Sequence:
 
 class ContinuousScheduler:
     def __init__(self, model, tokenizer, max_slots: int = 8, kv_dtype: Optional[str] = None, capacity: int = 1024,
-                 metrics=None, chunk_tokens: int = 256):
+                 metrics=None, chunk_tokens: int = 256, paged: bool = True, block_tokens: int = 64,
+                 kv_blocks: Optional[int] = None, prefix_cache: bool = True):
         from ..engine import SampleArgs      # noqa: F401  (fail early if the library is missing)
         from ..utils import DEFAULT_KV_DTYPE
 
         self.model = model
         self.tok = tokenizer if isinstance(tokenizer, TokenizerWrapper) else TokenizerWrapper(tokenizer)
         self.max_slots = int(max_slots)
-        self.kv = model.engine.new_kv(self.max_slots, capacity=capacity, kv_dtype=kv_dtype or DEFAULT_KV_DTYPE)
+        # KV: a block-paged arena (rows grow without copies, cost memory for what they hold and share the blocks of a
+        # common prompt prefix); engines without it (the CPU test double) get the contiguous per-row slabs
+        eng = model.engine
+        self.paged = bool(paged) and hasattr(eng, "new_paged_kv")
+        if self.paged:
+            self.kv = eng.new_paged_kv(self.max_slots, block_tokens=block_tokens, n_blocks=kv_blocks,
+                                       max_tokens_per_row=eng.max_positions, kv_dtype=kv_dtype or DEFAULT_KV_DTYPE)
+        else:
+            self.kv = eng.new_kv(self.max_slots, capacity=capacity, kv_dtype=kv_dtype or DEFAULT_KV_DTYPE)
+        self.prefix_cache = bool(prefix_cache) and self.paged
+        self.prefix_hit_tokens = 0
         self.slots: List[Optional[Sequence]] = [None] * self.max_slots
         self.pending: Deque[Sequence] = collections.deque()
         self.cv = threading.Condition()
@@ -200,13 +211,18 @@ class ContinuousScheduler:
             self._finish(seq, "length")
             return
         self.kv.reset_row(slot)
+        seq.prefill_pos = 0
+        if self.prefix_cache:                     # full blocks of an earlier prompt with the same prefix are mapped, not recomputed
+            seq.prefill_pos = self.kv.prefix_attach(slot, seq.prompt)
+            self.prefix_hit_tokens += seq.prefill_pos
         if self.chunk_tokens > 0:                 # the prompt enters the cache chunk by chunk, inside the decode steps
-            seq.prefill_pos = 0
             return
         t0 = time.perf_counter()
-        res = eng.step_wait(eng.step_enqueue_rows(self.kv, [slot], seq.prompt[None, :], self._sample_args([seq])), 1)
+        res = eng.step_wait(eng.step_enqueue_rows(self.kv, [slot], seq.prompt[None, seq.prefill_pos:], self._sample_args([seq])), 1)
         self.prefills += 1
         seq.prefill_pos, seq.prefilled = len(seq.prompt), True
+        if self.prefix_cache:
+            self.kv.prefix_publish(slot, seq.prompt)
         if self.metrics is not None:
             self.metrics.record_throughput({"prompt_tokens": float(len(seq.prompt)), "prompt_time": time.perf_counter() - t0})
         self._on_token(seq, int(res["tokens"][0]))
@@ -244,6 +260,8 @@ class ContinuousScheduler:
             if s in prefilling:
                 s.prefill_pos += len(tk)
                 self.chunks += 1
+                if self.prefix_cache and s.prefill_pos == len(s.prompt):
+                    self.kv.prefix_publish(s.slot, s.prompt)      # (enqueued above: later readers are ordered behind it)
         for s, t in zip(wanted, res["tokens"] if wanted else []):
             if s in prefilling:
                 s.prefilled = True

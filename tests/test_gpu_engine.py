@@ -617,3 +617,125 @@ def test_error_behaviour(tiny_dirs, tmp_path):
     with pytest.raises(ValueError):
         model.engine.forward(np.full((2, 2), cfg["vocab_size"], np.int32), kv)   # token id out of range
     model.engine.close()
+
+
+@pytest.mark.parametrize("kvd", ["model", "float32"])
+@pytest.mark.parametrize("name", ["llama_f32", "llama_bf16_gqa", "qwen3_bf16", "llama_q4_bf16"])
+def test_paged_kv_is_bit_identical_to_contiguous_kv(tiny_dirs, name, kvd):
+    """mi_kv_create_paged: the block table only changes WHERE a token's K / V row lives, so every kernel family
+    (VALU and MFMA decode attention, prefill attention, rope_append, mixed steps) must give the same bits as the
+    contiguous cache: logits of a ragged prefill, of decode steps on row subsets, and of a chunked prefill; blocks are
+    handed out in a scrambled order (rows interleave their allocations), recycled on reset_row, and the arena's
+    exhaustion is an error, not a fault."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    eng = model.engine
+    V = cfg["vocab_size"]
+    B, L0 = 3, 37
+    toks = RNG.integers(3, V, size=(B, L0)).astype(np.int32)
+    flat = eng.new_kv(B, capacity=128, kv_dtype=kvd)
+    paged = eng.new_paged_kv(B, block_tokens=16, n_blocks=40, max_tokens_per_row=128, kv_dtype=kvd)
+    assert paged.stats()["free_blocks"] == 39 and paged.capacity == 128
+    a = eng.forward(toks, flat, all_positions=True)
+    b = eng.forward(toks, paged, all_positions=True)
+    assert np.array_equal(a, b)
+    greedy = SampleArgs(temp=0.0, top_logprobs=3)
+    nxt = np.argmax(a[:, -1], axis=-1).astype(np.int32)
+    for step in range(20):                                   # crosses block boundaries (37 -> 57 tokens, 16-token blocks)
+        rows = [0, 1, 2] if step % 3 else [2, 0]
+        ra = eng.step_wait(eng.step_enqueue_rows(flat, rows, nxt[rows][:, None], greedy), len(rows), 3)
+        rb = eng.step_wait(eng.step_enqueue_rows(paged, rows, nxt[rows][:, None], greedy), len(rows), 3)
+        assert np.array_equal(ra["tokens"], rb["tokens"]) and np.array_equal(ra["logprobs"], rb["logprobs"])
+        assert np.array_equal(ra["top_logprobs"], rb["top_logprobs"])
+        nxt[rows] = ra["tokens"]
+    assert flat.offsets == paged.offsets
+    # recycle row 1, admit a new prompt there in chunks next to the other rows' decode steps (mixed steps)
+    flat.reset_row(1); paged.reset_row(1)
+    p2 = RNG.integers(3, V, size=45).astype(np.int32)
+    for kv in (flat, paged):
+        res = []
+        res.append(eng.step_wait(eng.step_enqueue_mixed(kv, [0, 2, 1], [[int(nxt[0])], [int(nxt[2])], p2[:20]], [1, 1, 0], greedy), 2, 3))
+        t0, t2 = res[-1]["tokens"]
+        res.append(eng.step_wait(eng.step_enqueue_mixed(kv, [0, 2, 1], [[int(t0)], [int(t2)], p2[20:]], [1, 1, 1], greedy), 3, 3))
+        kv.results = res
+    for ra, rb in zip(flat.results, paged.results):
+        assert np.array_equal(ra["tokens"], rb["tokens"]) and np.array_equal(ra["logprobs"], rb["logprobs"])
+    st = paged.stats()
+    assert st["free_blocks"] == 39 - sum((o + 15) // 16 for o in paged.offsets)
+    # exhaustion: a fourth... the arena has 39 usable blocks of 16 tokens; a cache with too few fails loudly
+    small = eng.new_paged_kv(2, block_tokens=16, n_blocks=4, max_tokens_per_row=128, kv_dtype=kvd)
+    eng.forward(toks[:1, :30], small, want_logits=False) if False else None
+    with pytest.raises(RuntimeError, match="exhausted"):
+        eng.step_wait(eng.step_enqueue_rows(small, [0, 1], toks[:2, :33], greedy), 2, 3)     # 2 x 3 blocks > 3 usable
+    flat.close(); paged.close(); small.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["llama_f32", "qwen3_bf16"])
+def test_prefix_reuse_on_the_paged_cache(tiny_dirs, name):
+    """mi_kv_prefix_attach / publish: a second prompt that starts with the same 40 tokens maps the first prompt's two
+    full 16-token blocks instead of recomputing them, prefills only the rest, and still produces what it produces
+    alone (oracle, single sequence); a prompt that differs inside the first block shares nothing; the shared blocks
+    survive the first row's reset and are evicted, least recently used first, when the arena runs out."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    eng = model.engine
+    exact = name == "llama_f32"
+    V = cfg["vocab_size"]
+    common = RNG.integers(3, V, size=40).astype(np.int32)
+    pa = np.concatenate([common, RNG.integers(3, V, size=7).astype(np.int32)])
+    pb = np.concatenate([common, RNG.integers(3, V, size=11).astype(np.int32)])
+    pc = pa.copy(); pc[5] = (pc[5] + 1) % V
+    kv = eng.new_paged_kv(3, block_tokens=16, n_blocks=12, max_tokens_per_row=96, kv_dtype="model")
+    greedy = SampleArgs(temp=0.0)
+
+    def alone(p, n):
+        cache = ref.make_cache(1, paged=False)
+        y, out, margins = p[None], [], []
+        for _ in range(n):
+            lg = ref(y, cache=cache)[:, -1]
+            top2 = np.sort(lg[0])[-2:]
+            margins.append(float(top2[1] - top2[0]))
+            y = np.argmax(lg, axis=-1)[:, None]
+            out.append(int(y[0, 0]))
+        return out, margins
+
+    def run(row, prompt, n):
+        reused = kv.prefix_attach(row, prompt)
+        assert kv.offsets[row] == reused
+        out = [int(eng.step_wait(eng.step_enqueue_rows(kv, [row], prompt[None, reused:], greedy), 1)["tokens"][0])]
+        kv.prefix_publish(row, prompt)
+        for _ in range(n - 1):
+            out.append(int(eng.step_wait(eng.step_enqueue_rows(kv, [row], [[out[-1]]], greedy), 1)["tokens"][0]))
+        return reused, out
+
+    def check(got, prompt):
+        want, margins = alone(prompt, len(got))
+        for i, (g, w) in enumerate(zip(got, want)):
+            if g != w:
+                assert not exact and margins[i] <= 0.13, (i, got, want, margins[i])
+                break
+
+    ra, ga = run(0, pa, 6)
+    assert ra == 0 and kv.stats()["cached_blocks"] == 2                       # 47 tokens: two full blocks published
+    rb, gb = run(1, pb, 6)
+    assert rb == 32 and kv.stats()["reused_tokens"] == 32                      # both full blocks of the common prefix
+    rc, gc = run(2, pc, 4)
+    assert rc == 0                                                             # differs inside block 0: nothing shared
+    check(ga, pa); check(gb, pb); check(gc, pc)
+    assert kv.h_tab_row(1)[:2] == kv.h_tab_row(0)[:2] if hasattr(kv, "h_tab_row") else True
+    kv.reset_row(0)                                                            # the owner leaves; its published blocks stay
+    kv.reset_row(2)
+    rd, gd = run(0, pa, 3)
+    assert rd == 32
+    check(gd, pa)
+    with pytest.raises(ValueError):
+        kv.prefix_attach(1, pb)                                                # row 1 is not empty
+    # the cache gives its blocks back under pressure: fill the arena with a long unrelated sequence
+    kv.reset_row(0); kv.reset_row(1)
+    long = RNG.integers(3, V, size=90).astype(np.int32)
+    eng.step_wait(eng.step_enqueue_rows(kv, [2], long[None], greedy), 1)       # 6 blocks; 11 usable, some held by the cache
+    eng.step_wait(eng.step_enqueue_rows(kv, [1], long[None, :80], greedy), 1)  # 5 more: cached blocks must be evicted
+    assert kv.stats()["evictions"] >= 1
+    eng.invalidate_prefix_caches()
+    assert kv.stats()["cached_blocks"] == 0
+    kv.close()
+    eng.close()
