@@ -166,6 +166,14 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only to rehearse N > 1 on a single-GPU box or on CPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--mode", default="decode", choices=["decode", "mixed"],
+                    help="decode: the headline metric (K decode steps of a full batch).  mixed: BASELINE config 5's 'mixed "
+                         "prefill + decode' -- every step decodes the live rows AND ingests a chunk of an arriving prompt in "
+                         "the same pass over the weights (mi_step_enqueue_mixed, block-paged KV), timed next to the unfused "
+                         "schedule (decode step, then the chunk on its own)")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="--mode mixed: prompt tokens ingested per step; 0 = what the live rows leave of the 128 rows (int4: 96) "
+                         "that the weight-streaming kernels serve with one read of W")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-process protocol without an engine (launch, rendezvous, bucketed weight "
                          "broadcast, barrier / max-over-ranks timing) -- the only mode that runs without a GPU; "
@@ -223,6 +231,77 @@ def decode_leg(engine, cfg, args, kv_dtype, prompts, sample, dist, world, cap):
     engine.profile_select(None)
     kv.close()
     return dict(elapsed=elapsed, t_prefill=t_prefill, n_launch=n_launch, total_ms=total_ms)
+
+
+def mixed_leg(engine, cfg, args, sample, dist, world):
+    """Steady state of a serving batch: B slots, B - 1 of them decoding at context ~args.context, one slot taking in
+    the prompt of the next request `--chunk` tokens per step; when a prompt is complete it starts decoding and the
+    oldest sequence leaves (its row is reset for the next arrival).  Returns timings of K such steps, fused (one
+    mi_step_enqueue_mixed per step) and unfused (a decode step of the live rows + the chunk as a step of its own)."""
+    import numpy as np
+    import torch
+
+    B, K, W, ctx, C = args.batch, args.steps, args.warmup, args.context, args.chunk
+    rng = np.random.default_rng(args.seed + 5)
+    V = cfg["vocab_size"]
+    out = {}
+    for fused in (True, False):
+        kv = engine.new_paged_kv(B, block_tokens=64, max_tokens_per_row=ctx + K + W + 2 * C + 64, kv_dtype=args.kv_dtype)
+        # B - 1 live sequences with `ctx` tokens each (prefilled 8 rows at a time), row B - 1 is the arrival slot
+        live = list(range(B - 1))
+        last = np.zeros(B, dtype=np.int32)
+        for i in range(0, B - 1, 8):
+            rows = live[i:i + 8]
+            p = rng.integers(0, V, size=(len(rows), ctx)).astype(np.int32)
+            res = engine.step_wait(engine.step_enqueue_rows(kv, rows, p, sample), len(rows))
+            last[rows] = res["tokens"]
+        arriving, pos = B - 1, 0
+        prompt = rng.integers(0, V, size=ctx).astype(np.int32)
+
+        def one_step():
+            nonlocal arriving, pos, prompt, live
+            chunk = prompt[pos:pos + C]
+            done = pos + len(chunk) >= len(prompt)
+            if fused:
+                t = engine.step_enqueue_mixed(kv, live + [arriving], [[int(last[r])] for r in live] + [chunk], [1] * len(live) + [int(done)], sample)
+                res = engine.step_wait(t, len(live) + int(done))
+                last[live] = res["tokens"][:len(live)]
+                if done:
+                    last[arriving] = res["tokens"][-1]
+            else:
+                t1 = engine.step_enqueue_rows(kv, live, [[int(last[r])] for r in live], sample)
+                t2 = engine.step_enqueue_mixed(kv, [arriving], [chunk], [int(done)], sample)
+                last[live] = engine.step_wait(t1, len(live))["tokens"]
+                r2 = engine.step_wait(t2, int(done))
+                if done:
+                    last[arriving] = r2["tokens"][-1]
+            pos += len(chunk)
+            if done:                                    # the new sequence joins, the oldest leaves and frees its row
+                oldest = live.pop(0)
+                live.append(arriving)
+                kv.reset_row(oldest)
+                arriving, pos = oldest, 0
+                prompt = rng.integers(0, V, size=ctx).astype(np.int32)
+            return len(chunk)
+
+        for _ in range(W):
+            one_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); engine.sync()
+        t0 = time.perf_counter()
+        ptoks = sum(one_step() for _ in range(K))
+        engine.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        out["fused" if fused else "unfused"] = dict(elapsed=el, prompt_tokens=ptoks, decode_tokens=(B - 1) * K, kv_stats=kv.stats())
+        kv.close()
+    return out
 
 
 def main():
@@ -309,6 +388,10 @@ def main():
 
     from mlx_parallm_amd.engine import Engine, SampleArgs
 
+    if args.mode == "mixed":
+        if args.chunk <= 0:
+            args.chunk = max(16, (96 if quant_bits == 4 else 128) - (B - 1) - 1)
+        cap = ctx + K + W + 2 * args.chunk + 128
     engine = Engine(cfg, device=local_rank, max_positions=max(cap, 2048), act_dtype="bfloat16")
     for kv_ in args.opt:
         k_, v_ = kv_.split("=")
@@ -332,6 +415,35 @@ def main():
     # greedy for the bf16 configurations (BASELINE configs 2, 4); top-p 0.9 at temperature 1 with
     # log-probabilities for the int4 configuration (config 3).  `greedy` names the per-step sampler either way.
     greedy = SampleArgs(temp=1.0, top_p=0.9, seed=args.seed) if (quant_bits and not args.greedy) else SampleArgs(temp=0.0)
+
+    if args.mode == "mixed":
+        m = mixed_leg(engine, cfg, args, greedy, dist, world)
+        if rank == 0:
+            f, u = m["fused"], m["unfused"]
+            w_bytes, _ = streamed_weight_bytes(cfg, quant_bits)
+            print(json.dumps({
+                "metric": "decode_tokens_per_sec", "value": round(world * f["decode_tokens"] / f["elapsed"], 2), "unit": "tokens/s",
+                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(f["elapsed"] / K * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16" if not quant_bits else f"int{quant_bits}-g64 weights, bf16 activations",
+                "data": "synthetic token ids; random-init weights N(0,0.02^2)",
+                "config": {"workload": f"{family} shape ({args.workload}), MIXED prefill + decode: {B - 1} live sequences/GPU decoding at KV length ~{ctx} "
+                                       f"while the prompt of the next request enters the cache {args.chunk} tokens per step in the SAME pass "
+                                       f"over the weights (mi_step_enqueue_mixed, block-paged KV, 64-token blocks)"
+                                       + (f", rank-16 LoRA on q/v of the last {args.lora} layers" if args.lora else ""),
+                           "batch_per_gpu": B, "global_batch": B * world, "context": ctx, "chunk_tokens": args.chunk,
+                           "kv_dtype": args.kv_dtype, "parallelism": f"dp{world} (batch-sharded replicas, no collective in the step)"},
+                "prefill_tokens_per_sec_in_the_same_steps": round(world * f["prompt_tokens"] / f["elapsed"], 1),
+                "unfused_schedule": {"what": "the same K steps as a decode step of the live rows followed by the chunk as a step of its own (two passes over the weights)",
+                                     "decode_tokens_per_sec": round(world * u["decode_tokens"] / u["elapsed"], 2),
+                                     "ms_per_step": round(u["elapsed"] / K * 1e3, 4)},
+                "fused_over_unfused": round(u["elapsed"] / f["elapsed"], 3),
+                "weight_bytes_per_step": int(w_bytes), "kv_arena": f["kv_stats"], "load_seconds": round(t_load, 2), "ranks_seen": ranks_seen,
+            }), flush=True)
+        engine.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     head = decode_leg(engine, cfg, args, args.kv_dtype, prompts, greedy, dist, world, cap)
     other_mode = "float32" if args.kv_dtype == "model" else "model"

@@ -14,6 +14,7 @@
 //   * splits publish (max, sum, O) partials and take a ticket; the last arriver of a
 //     (sequence, kv-head) combines them (agent-scope release -> ticket -> acquire; nobody waits).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemv_phase.h"
@@ -70,6 +71,38 @@ __device__ __forceinline__ void raw_to_f32(const uint32_t (&r)[NW32], float (&o)
       o[2 * e] = (float)h.x; o[2 * e + 1] = (float)h.y;
     }
   }
+}
+
+
+// The last split's combine: (max, sum, O[d]) of every split for one (head, d).  The loads of four splits are issued
+// together (a loop over a run-time split count with the loads inside waits one L2 round trip per load: ~8 in a row
+// for 4 splits), then merged in split order -- deterministic whoever arrived last.
+template <int D>
+__device__ __forceinline__ float combine_splits(const float* pp, int nsplit, int d) {
+  float mn = -1e30f, L = 0.f, O = 0.f;
+  for (int i0 = 0; i0 < nsplit; i0 += 4) {
+    float mv[4], lv[4], ov[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* q = pp + (size_t)min(i0 + j, nsplit - 1) * (D + 2);
+      mv[j] = __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lv[j] = __hip_atomic_load(&q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ov[j] = __hip_atomic_load(&q[2 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float bm = mn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (i0 + j < nsplit) bm = fmaxf(bm, mv[j]);
+    const float cs = __builtin_amdgcn_exp2f(mn - bm);
+    L *= cs; O *= cs; mn = bm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < nsplit) {
+        const float cw = __builtin_amdgcn_exp2f(mv[j] - mn);
+        L = fmaf(lv[j], cw, L);
+        O = fmaf(ov[j], cw, O);
+      }
+  }
+  return O / L;
 }
 
 // D must be a multiple of 32 for 16-bit caches (two elements per dword per lane); float caches any D % 16 == 0
@@ -340,18 +373,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
   for (int idx = tid; idx < G * D; idx += 512) {
     const int g = idx / D, d = idx % D, h = kh * G + g;
     const float* pp = c.partial + ((size_t)b * s.Hq + h) * c.nsplit * (D + 2);
-    float mn = -1e30f;
-    for (int i = 0; i < c.nsplit; ++i) mn = fmaxf(mn, __hip_atomic_load(&pp[i * (D + 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    float L = 0.f, O = 0.f;
-    for (int i = 0; i < c.nsplit; ++i) {
-      const float mi_ = __hip_atomic_load(&pp[i * (D + 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float li_ = __hip_atomic_load(&pp[i * (D + 2) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float oi_ = __hip_atomic_load(&pp[i * (D + 2) + 2 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float cw = __builtin_amdgcn_exp2f(mi_ - mn);
-      L = fmaf(li_, cw, L);
-      O = fmaf(oi_, cw, O);
-    }
-    out[(size_t)h * D + d] = store_act<T>(O / L, c.rnd_out);
+    out[(size_t)h * D + d] = store_act<T>(combine_splits<D>(pp, c.nsplit, d), c.rnd_out);
   }
 }
 
@@ -393,14 +415,14 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
-template <int G, int D, int ES = 2>
-__host__ __device__ constexpr size_t attn_mfma_vimg_bytes() { return ES == 2 ? (size_t)8 * 32 * D * 2 : 0; }   // float32 caches: no V image
+template <int G, int D, int ES = 2, int NWV = 8>
+__host__ __device__ constexpr size_t attn_mfma_vimg_bytes() { return ES == 2 ? (size_t)NWV * 32 * D * 2 : 0; }   // float32 caches: no V image
 
-template <int G, int D, int ES = 2>
+template <int G, int D, int ES = 2, int NWV = 8>
 __host__ __device__ constexpr size_t attn_mfma_lds_bytes() {
-  // [V images: 8 waves x 32 keys x D x 2 B (16-bit caches only)][q + new key: (G + 1) x D x ES B][st_o: 9 x G x D floats]
-  // [st_m, st_l: 9 x G floats each]
-  return attn_mfma_vimg_bytes<G, D, ES>() + (size_t)(G + 1) * D * ES + (size_t)9 * G * D * 4 + (size_t)2 * 9 * G * 4 + 16;
+  // [V images: NWV waves x 32 keys x D x 2 B (16-bit caches only)][q + new key: (G + 1) x D x ES B]
+  // [st_o: (NWV + 1) x G x D floats][st_m, st_l: (NWV + 1) x G floats each]
+  return attn_mfma_vimg_bytes<G, D, ES, NWV>() + (size_t)(G + 1) * D * ES + (size_t)(NWV + 1) * G * D * 4 + (size_t)2 * (NWV + 1) * G * 4 + 16;
 }
 
 // float32 caches (the PagedKVCache mode, base.py:104-140): v_mfma_f32_16x16x4_f32 -- exact float32 products, one float per
@@ -437,11 +459,14 @@ __device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
 // and measured SLOWER than two launches -- 36.7 us with the weights prefetched from `after_loads`, 33.7 us
 // prefetched after the attention, against 19.6 + 12.1 us: the per-CU memory queue is in order, so the 128 KiB
 // of weight loads per CU sit in front of every dependent load of the attention's latency chain.  Dropped.
-template <typename T, int D, int G, bool NORM, bool WT, bool PAGED, class Hook>
+// NWV = waves per workgroup: 8, or 12 (768 threads, three waves per SIMD, <= 168 registers) when that lets every
+// workgroup cover its share of the keys in ONE round -- 4 splits x 12 waves x 32 keys = 1536 keys, e.g. the contexts
+// just above 1024 where eight waves pay a second, nearly empty round.
+template <typename T, int D, int G, bool NORM, bool WT, bool PAGED, int NWV, class Hook>
 __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, unsigned char* smem, Hook after_loads) {
   constexpr bool F32 = sizeof(T) == 4;
   static_assert(D % 32 == 0 && D <= 128 && G <= 8 && (!F32 || D % 64 == 0), "16-bit caches: head_dim 32/64/96/128; float32: 64/128");
-  constexpr int EPL = D / 16, NWV = 8, NW32 = EPL * (int)sizeof(T) / 4;
+  constexpr int EPL = D / 16, NW32 = EPL * (int)sizeof(T) / 4, NTH = NWV * 64;
   constexpr int KK = D / 32, DT = D / 16, NV = (32 * D * 2) / (64 * 16);   // K steps, 16-d tiles, 16-B V loads per lane
   constexpr int KPW = F32 ? 16 : 32;             // keys per wave and round
   constexpr int NP = D / 16, NH = D / 64 > 0 ? D / 64 : 1;   // float32: 16-byte K pieces per lane and tile, 64-d halves of a V row
@@ -464,13 +489,13 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   const int nq = s.Hq * D;
   const T* row = (const T*)c.qkv + (size_t)b * (nq + 2 * s.Hkv * D);
 
-  constexpr size_t VIMG = attn_mfma_vimg_bytes<G, D, (int)sizeof(T)>();
+  constexpr size_t VIMG = attn_mfma_vimg_bytes<G, D, (int)sizeof(T), NWV>();
   unsigned char* vimg = smem + (size_t)wave * (32 * D * 2);          // this wave's V image (16-bit caches)
   T* q_sh = (T*)(smem + VIMG);                                        // [G + 1][D]: q heads, then the new key
-  float* st_o = (float*)(smem + VIMG + (size_t)(G + 1) * D * sizeof(T));   // [9][G][D]
-  float* st_m = st_o + 9 * G * D;                                     // [9][G]
-  float* st_l = st_m + 9 * G;
-  int& is_last_sh = *(int*)(st_l + 9 * G);       // (no static __shared__ in front of the dynamic region)
+  float* st_o = (float*)(smem + VIMG + (size_t)(G + 1) * D * sizeof(T));   // [NWV + 1][G][D]
+  float* st_m = st_o + (NWV + 1) * G * D;                             // [NWV + 1][G]
+  float* st_l = st_m + (NWV + 1) * G;
+  int& is_last_sh = *(int*)(st_l + (NWV + 1) * G);       // (no static __shared__ in front of the dynamic region)
 
   T* kc = (T*)c.kcache;                          // + kv_elem(row, head, key): contiguous slabs or the block arena
   T* vc = (T*)c.vcache;
@@ -585,7 +610,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) st_o[(8 * G + g) * D + li * EPL + e] = owner ? vf[e] : 0.f;
+      for (int e = 0; e < EPL; ++e) st_o[(NWV * G + g) * D + li * EPL + e] = owner ? vf[e] : 0.f;
   }
   const float sc2 = c.scale * LOG2E;
   __syncthreads();
@@ -606,7 +631,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
         for (int i = 0; i < NW32; ++i) d = dot2<T>(kn[i], ((const uint32_t*)(q_sh + (size_t)g * D + li * EPL))[i], d);
       }
       d = row16_sum(d) * sc2;
-      if (li == 0 && gq + 4 * j < G) { st_m[8 * G + g] = owner ? d : -1e30f; st_l[8 * G + g] = owner ? 1.f : 0.f; }
+      if (li == 0 && gq + 4 * j < G) { st_m[NWV * G + g] = owner ? d : -1e30f; st_l[NWV * G + g] = owner ? 1.f : 0.f; }
     }
   }
   u32x4 qf[F32 ? 1 : KK];
@@ -748,7 +773,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   }
   __syncthreads();
   T* out = (T*)c.out + (size_t)b * nq;
-  for (int idx = tid; idx < G * D; idx += 512) {
+  for (int idx = tid; idx < G * D; idx += NTH) {
     const int g = idx / D, d = idx % D;
     float mn = -1e30f;
 #pragma unroll
@@ -783,44 +808,41 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   }
   __syncthreads();
   if (!is_last_sh) return;
-  for (int idx = tid; idx < G * D; idx += 512) {
+  for (int idx = tid; idx < G * D; idx += NTH) {
     const int g = idx / D, d = idx % D, h = kh * G + g;
     const float* pp = c.partial + ((size_t)b * s.Hq + h) * c.nsplit * (D + 2);
-    float mn = -1e30f;
-    for (int i = 0; i < c.nsplit; ++i) mn = fmaxf(mn, __hip_atomic_load(&pp[i * (D + 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    float L = 0.f, O = 0.f;
-    for (int i = 0; i < c.nsplit; ++i) {
-      const float mi_ = __hip_atomic_load(&pp[i * (D + 2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float li_ = __hip_atomic_load(&pp[i * (D + 2) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float oi_ = __hip_atomic_load(&pp[i * (D + 2) + 2 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float cw = __builtin_amdgcn_exp2f(mi_ - mn);
-      L = fmaf(li_, cw, L);
-      O = fmaf(oi_, cw, O);
-    }
-    store_out<T>(&out[(size_t)h * D + d], store_act<T>(O / L, c.rnd_out), WT);
+    store_out<T>(&out[(size_t)h * D + d], store_act<T>(combine_splits<D>(pp, c.nsplit, d), c.rnd_out), WT);
   }
 }
 
-template <typename T, int D, int G, bool NORM, bool PAGED>
-__global__ __launch_bounds__(512) void attn_decode_mfma_kernel(AttnDecodeCall c) {
+template <typename T, int D, int G, bool NORM, bool PAGED, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_decode_mfma_kernel(AttnDecodeCall c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  attn_decode_mfma_body<T, D, G, NORM, false, PAGED>(c, smem, NoHook{});
+  attn_decode_mfma_body<T, D, G, NORM, false, PAGED, NWV>(c, smem, NoHook{});
 }
 
 template <typename T, int D, int G, bool NORM>
 int launch_mfma_g(const AttnDecodeCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
-  const dim3 grid(c.nsplit, s.B * s.Hkv), block(512);
-  constexpr size_t lds = attn_mfma_lds_bytes<G, D, (int)sizeof(T)>();
-  if (s.btab) {
-    auto kern = attn_decode_mfma_kernel<T, D, G, NORM, true>;
-    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, c);
-  } else {
-    auto kern = attn_decode_mfma_kernel<T, D, G, NORM, false>;
-    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, c);
+  const dim3 grid(c.nsplit, s.B * s.Hkv);
+  // twelve waves where eight would need a second round and twelve do not (the host knows the row lengths)
+  constexpr int KPW = sizeof(T) == 4 ? 16 : 32;
+  bool wide = c.variant == 2;                    // (variant 2: always twelve waves -- kernel tests)
+  if (!wide && c.n_host_off > 0) {
+    int mx = 0;
+    for (int b = 0; b < c.n_host_off; ++b) mx = std::max(mx, c.host_off[b]);
+    const int chunk = (mx + c.nsplit - 1) / c.nsplit;
+    static const bool allow = getenv("MI_ATTN_NO_WIDE") == nullptr;
+    wide = allow && (chunk + KPW * 8 - 1) / (KPW * 8) > (chunk + KPW * 12 - 1) / (KPW * 12);
   }
+#define LAUNCH_MFMA(PG, NW) do { \
+    auto kern = attn_decode_mfma_kernel<T, D, G, NORM, PG, NW>; \
+    constexpr size_t lds = attn_mfma_lds_bytes<G, D, (int)sizeof(T), NW>(); \
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, c); } while (0)
+  if (s.btab) { if (wide) LAUNCH_MFMA(true, 12); else LAUNCH_MFMA(true, 8); }
+  else { if (wide) LAUNCH_MFMA(false, 12); else LAUNCH_MFMA(false, 8); }
+#undef LAUNCH_MFMA
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -771,7 +771,10 @@ int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* l
       return fail(MI_ERR_INVALID, "mixed step: KV capacity / max_positions exceeded (call mi_kv_reserve)");
     tok0[i] = R; R += (size_t)lens[i];
   }
-  e->cur_L = R == (size_t)nd ? 1 : 2;            // only decode rows: the decode step's kernels; else the prefill path's
+  // Up to 128 tokens in all (decode rows + chunks) the linears stay the decode step's weight-streaming kernels: ONE read
+  // of W for every row (gemm_skinny.hip serves 1..128 rows; a 256-row tile GEMM would leave most CUs idle at this
+  // size and cost more than the weights' stream).  Larger steps take the prefill path's tile GEMM.
+  e->cur_L = R <= 128 ? 1 : 2;
   e->sq_valid = false;
   if (!kv->d_rows) MI_HIP(hipMalloc(&kv->d_rows, kv->B * sizeof(int32_t)));
   MI_HIP(hipMemcpyAsync(kv->d_rows, rows, n * sizeof(int32_t), hipMemcpyHostToDevice, st));

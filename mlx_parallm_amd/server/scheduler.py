@@ -65,7 +65,7 @@ class Sequence:
 class ContinuousScheduler:
     def __init__(self, model, tokenizer, max_slots: int = 8, kv_dtype: Optional[str] = None, capacity: int = 1024,
                  metrics=None, chunk_tokens: int = 256, paged: bool = True, block_tokens: int = 64,
-                 kv_blocks: Optional[int] = None, prefix_cache: bool = True):
+                 kv_blocks: Optional[int] = None, prefix_cache: bool = True, step_rows: int = 128):
         from ..engine import SampleArgs      # noqa: F401  (fail early if the library is missing)
         from ..utils import DEFAULT_KV_DTYPE
 
@@ -100,6 +100,10 @@ class ContinuousScheduler:
         # the SAME pass over the weights as the live rows' decode step (engine.step_enqueue_mixed).  0 = the older
         # behaviour: the whole prompt is prefilled alone while the live rows wait.
         self.chunk_tokens = int(chunk_tokens) if hasattr(model.engine, "step_enqueue_mixed") else 0
+        # tokens per mixed step (decode rows + chunk tokens): up to 128 the engine streams every weight matrix once for all
+        # of them (its decode kernels serve 1..128 rows; int4 SwiGLU: 96), so the chunk budget of a step is what the live
+        # rows leave of this
+        self.step_rows = int(step_rows)
         self.mixed_steps = 0               # steps that carried prompt chunks next to decode rows
         self.chunks = 0
 
@@ -236,6 +240,8 @@ class ContinuousScheduler:
         for s in decoding:
             rows.append(s.slot); toks.append([s.last_token]); want.append(1); who.append(s)
         budget = self.chunk_tokens
+        if self.step_rows > 0:
+            budget = max(16, min(budget, self.step_rows - len(decoding)))
         n_chunk_tokens = 0
         for s in prefilling:
             if budget <= 0:

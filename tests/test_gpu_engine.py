@@ -661,9 +661,8 @@ def test_paged_kv_is_bit_identical_to_contiguous_kv(tiny_dirs, name, kvd):
         assert np.array_equal(ra["tokens"], rb["tokens"]) and np.array_equal(ra["logprobs"], rb["logprobs"])
     st = paged.stats()
     assert st["free_blocks"] == 39 - sum((o + 15) // 16 for o in paged.offsets)
-    # exhaustion: a fourth... the arena has 39 usable blocks of 16 tokens; a cache with too few fails loudly
+    # exhaustion: an arena with too few blocks for the step fails loudly
     small = eng.new_paged_kv(2, block_tokens=16, n_blocks=4, max_tokens_per_row=128, kv_dtype=kvd)
-    eng.forward(toks[:1, :30], small, want_logits=False) if False else None
     with pytest.raises(RuntimeError, match="exhausted"):
         eng.step_wait(eng.step_enqueue_rows(small, [0, 1], toks[:2, :33], greedy), 2, 3)     # 2 x 3 blocks > 3 usable
     flat.close(); paged.close(); small.close()
@@ -721,7 +720,6 @@ def test_prefix_reuse_on_the_paged_cache(tiny_dirs, name):
     rc, gc = run(2, pc, 4)
     assert rc == 0                                                             # differs inside block 0: nothing shared
     check(ga, pa); check(gb, pb); check(gc, pc)
-    assert kv.h_tab_row(1)[:2] == kv.h_tab_row(0)[:2] if hasattr(kv, "h_tab_row") else True
     kv.reset_row(0)                                                            # the owner leaves; its published blocks stay
     kv.reset_row(2)
     rd, gd = run(0, pa, 3)
