@@ -231,6 +231,8 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *                             staging of the next instead of an rmsnorm launch (default 0: measured neutral)
  *   "defer_norm"              0: float32-activation (PagedKVCache mode) decode steps run the RMSNorm as its own launch
  *                             instead of applying its row scale in the epilogue of the linear behind it (default 1)
+ *   "short_prefill_skinny"    0: prefill calls of <= 128 rows in all through the tile GEMM like longer ones (default 1: the
+ *                             weight-streaming split-K kernel of the decode steps, ~2x faster at that size)
  *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1)
  * Environment switches read once by the library (A/B runs only): MI_SKINNY_MIN_ROWS (hand-over row count for 16-bit
  * weights, default 9), MI_SKINNY_Q4_MIN_ROWS (set: int4 hands over like 16-bit), MI_SKINNY_NO_F32 (set: float32-KV mode

@@ -101,8 +101,8 @@ int mi_op_attention(const mi_op_attn_shape* s, const void* q, const void* kcache
                     const int32_t* offsets, void* out, float scale, int nsplit, float* partial);
 /* fused decode attention (L == 1): q/k norm + RoPE + append + split-KV attention + combine.
  * counters: [B*Hkv] zero-initialised ints.  variant 0: MFMA kernel where it applies (16-bit caches,
- * head_dim % 32 == 0; float32 caches, head_dim 64 / 128), 1: VALU kernel, 2: the MFMA kernel in its twelve-wave form
- * (which the engine picks when that saves a round of keys).  iters > 1 repeats the launch (timing; avg_ms may be NULL). */
+ * head_dim % 32 == 0; float32 caches, head_dim 64 / 128), 1: VALU kernel (2: the MFMA kernel in its twelve-wave form,
+ * only in a library built with -DMI_ATTN_WIDE; otherwise the same as 0).  iters > 1 repeats the launch (timing; avg_ms may be NULL). */
 int mi_op_attention_decode(const mi_op_attn_shape* s, const void* qkv, void* kcache, void* vcache,
                            const int32_t* offsets, const void* q_norm_w, const void* k_norm_w, float eps,
                            const float* cos_tab, const float* sin_tab, void* out, float scale, int rnd_out,

@@ -459,9 +459,12 @@ __device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
 // and measured SLOWER than two launches -- 36.7 us with the weights prefetched from `after_loads`, 33.7 us
 // prefetched after the attention, against 19.6 + 12.1 us: the per-CU memory queue is in order, so the 128 KiB
 // of weight loads per CU sit in front of every dependent load of the attention's latency chain.  Dropped.
-// NWV = waves per workgroup: 8, or 12 (768 threads, three waves per SIMD, <= 168 registers) when that lets every
-// workgroup cover its share of the keys in ONE round -- 4 splits x 12 waves x 32 keys = 1536 keys, e.g. the contexts
-// just above 1024 where eight waves pay a second, nearly empty round.
+// NWV = waves per workgroup: 8.  A twelve-wave form (768 threads, three waves per SIMD, <= 168 registers) that covers
+// 4 splits x 12 waves x 32 keys = 1536 keys in ONE round -- the contexts just above 1024, where eight waves pay a second,
+// nearly empty round -- was built, oracle-tested and MEASURED on the bench (KV 1032 -> 1100): bf16 caches 2251 vs
+// 2257 tok/s, float32 caches 1928 vs 1962: the extra round of eight waves costs less than four more waves' prologue,
+// LDS merge (13 slots) and the third wave per SIMD.  Kept behind -DMI_ATTN_WIDE (compile-time: it doubles this file's
+// instantiations), not built by default.
 template <typename T, int D, int G, bool NORM, bool WT, bool PAGED, int NWV, class Hook>
 __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, unsigned char* smem, Hook after_loads) {
   constexpr bool F32 = sizeof(T) == 4;
@@ -827,7 +830,9 @@ int launch_mfma_g(const AttnDecodeCall& c, hipStream_t st) {
   const dim3 grid(c.nsplit, s.B * s.Hkv);
   // twelve waves where eight would need a second round and twelve do not (the host knows the row lengths)
   constexpr int KPW = sizeof(T) == 4 ? 16 : 32;
-  bool wide = c.variant == 2;                    // (variant 2: always twelve waves -- kernel tests)
+  bool wide = false;
+#ifdef MI_ATTN_WIDE
+  wide = c.variant == 2;                         // (variant 2: always twelve waves -- kernel tests)
   if (!wide && c.n_host_off > 0) {
     int mx = 0;
     for (int b = 0; b < c.n_host_off; ++b) mx = std::max(mx, c.host_off[b]);
@@ -835,13 +840,19 @@ int launch_mfma_g(const AttnDecodeCall& c, hipStream_t st) {
     static const bool allow = getenv("MI_ATTN_NO_WIDE") == nullptr;
     wide = allow && (chunk + KPW * 8 - 1) / (KPW * 8) > (chunk + KPW * 12 - 1) / (KPW * 12);
   }
+#endif
 #define LAUNCH_MFMA(PG, NW) do { \
     auto kern = attn_decode_mfma_kernel<T, D, G, NORM, PG, NW>; \
     constexpr size_t lds = attn_mfma_lds_bytes<G, D, (int)sizeof(T), NW>(); \
     MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, c); } while (0)
+#ifdef MI_ATTN_WIDE
   if (s.btab) { if (wide) LAUNCH_MFMA(true, 12); else LAUNCH_MFMA(true, 8); }
   else { if (wide) LAUNCH_MFMA(false, 12); else LAUNCH_MFMA(false, 8); }
+#else
+  (void)wide; (void)KPW;
+  if (s.btab) LAUNCH_MFMA(true, 8); else LAUNCH_MFMA(false, 8);
+#endif
 #undef LAUNCH_MFMA
   MI_HIP(hipGetLastError());
   return MI_OK;

@@ -111,6 +111,7 @@ struct mi_engine {
   // leaves the rows' sums of squares, the normalised linear behind it uses them instead of an rmsnorm launch
   int opt_norm_handover = 0;    // measured neutral (int4 / int8 +-1 %, Qwen3-14B int4 -3.6 %): off by default
   int opt_defer_norm = 1;       // float32 activations: RMSNorm row scale applied in the split-K kernel's epilogue (no norm launch)
+  int opt_short_prefill_skinny = 1;   // prefill calls of <= 128 rows in all on the weight-streaming kernel instead of the tile GEMM
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
   bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0;
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
@@ -322,10 +323,13 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   c.force_v1 = e->opt_force_v1;
   const bool sq_was_valid = e->sq_valid;      // whatever runs now consumes or invalidates the hand-over
   e->sq_valid = false;
-  if (e->opt_skinny_gemm && e->cur_L == 1 && gemm_skinny_supported(f.W, c, rows)) {
+  if (e->opt_skinny_gemm && (e->cur_L == 1 || (rows <= 128 && e->opt_short_prefill_skinny)) && gemm_skinny_supported(f.W, c, rows)) {
     // the decode step of a batch of 9..128 sequences (int4 / int8 weights: any batch up to 128): W is streamed once, K split over workgroups (gemm_skinny.hip).
-    // Decode only: a prefill keeps ONE arithmetic whatever the batch around a sequence (the tile GEMM from 32 rows
-    // up, 16-row launches below), which tests/test_gpu_fullsize.py holds bit for bit.
+    // Also a prefill of up to 128 rows in all (a short prompt, a few short prompts): at that size the op is a weight
+    // stream, not a GEMM -- measured on Mistral-7B bf16, one prompt of 64 tokens: 13.0 ms through the 128 x 128 tile GEMM
+    // (32 workgroups for N = 4096) against ~6 ms here.  The price: a sequence's prefill arithmetic (summation order) now
+    // depends on whether the whole call is above or below 128 rows; inside one regime rows stay bit-independent of
+    // their neighbours (tests/test_gpu_fullsize.py).
     Prof pr(e, prof);
     // (float32 activations: the split-K kernel neither leaves nor takes the row statistics -- always the norm launch)
     const bool handed = sq_was_valid && e->opt_norm_handover && c.act != MI_F32 && c.pro == PRO_NORM && rows <= 16 &&
@@ -1537,6 +1541,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "skinny_gemm") { e->opt_skinny_gemm = value != 0; return MI_OK; }
   if (k == "norm_handover") { e->opt_norm_handover = value != 0; return MI_OK; }
   if (k == "defer_norm") { e->opt_defer_norm = value != 0; return MI_OK; }
+  if (k == "short_prefill_skinny") { e->opt_short_prefill_skinny = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "tile_weights") {

@@ -641,7 +641,11 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
   const int ncols = sw ? c.pair_offset : W.N;
   static const bool small_only = getenv("MI_GEMM_TILE128") != nullptr;        // A/B: always the 128 x 128 kernel
   static const bool b_in_lds = getenv("MI_GEMM_B_DIRECT") == nullptr;         // A/B: set = W fragments straight from global
-  if (rows >= 256 && !small_only) {                      // both operands through LDS (gemm_tile256_kernel)
+  // The 256 x 256 tile only where its grid fills the chip: at 8 x 1024 rows every linear has >= 512 blocks, but one prompt
+  // of 256..1024 tokens gives N/256 x (1..4) blocks -- 16..64 for N = 4096 -- and measured 25 / 25 / 30 ms for 256 / 512 /
+  // 1024 tokens against 14 / 17 / 23 ms on the 128 x 128 tile (Mistral-7B bf16; tools/debug/prefill_sweep.py).
+  const long blocks256 = (long)(((int)rows + BM2 - 1) / BM2) * ((ncols + (sw ? 128 : BN2) - 1) / (sw ? 128 : BN2));
+  if (rows >= 256 && !small_only && blocks256 >= 192) {  // both operands through LDS (gemm_tile256_kernel)
     const int bn = sw ? 128 : BN2;
     const dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
 #define GO256(T, S) do { \

@@ -241,7 +241,7 @@ class ContinuousScheduler:
             rows.append(s.slot); toks.append([s.last_token]); want.append(1); who.append(s)
         budget = self.chunk_tokens
         if self.step_rows > 0:
-            budget = max(16, min(budget, self.step_rows - len(decoding)))
+            budget = min(budget, max(16, self.step_rows - len(decoding)))
         n_chunk_tokens = 0
         for s in prefilling:
             if budget <= 0:

@@ -57,7 +57,7 @@ def _greedy(eng, prompts, steps, **opts):
     kv.close()
     for k in opts:
         eng.set_option(k, {"force_generic_gemv": 0, "fused_decode_attention": 1, "prefill_gemm": 1,
-                           "decode_attention_mfma": 1, "fused_gemv_pairs": 0, "skinny_gemm": 1}[k])
+                           "decode_attention_mfma": 1, "fused_gemv_pairs": 0, "skinny_gemm": 1, "short_prefill_skinny": 1}[k])
     return np.stack(toks), lg
 
 
@@ -94,7 +94,9 @@ def test_mfma_path_agrees_with_exact_valu_path(big):
 def test_rows_are_independent_and_runs_are_deterministic(big):
     eng, cfg = big
     rng = np.random.default_rng(4)
-    p = rng.integers(0, cfg["vocab_size"], size=(8, 64)).astype(np.int32)
+    # 160-token prompts: alone (160 rows) and in a batch (1280 rows) both run the tile GEMM.  (Calls of <= 128 rows in all
+    # take the weight-streaming kernel instead -- another summation order -- see test_short_prefill_on_the_streaming_kernel.)
+    p = rng.integers(0, cfg["vocab_size"], size=(8, 160)).astype(np.int32)
     p[5] = p[2]                                           # the same sequence twice in one batch
     a, la = _greedy(eng, p, 8)
     b, lb = _greedy(eng, p, 8)
@@ -103,9 +105,40 @@ def test_rows_are_independent_and_runs_are_deterministic(big):
     solo, ls = _greedy(eng, p[2:3], 8)
     assert np.array_equal(solo[:, 0], a[:, 2]) and np.array_equal(ls[0], la[2])  # alone == inside a batch of 8
     q = p.copy()
-    q[[0, 1, 3, 4, 6, 7]] = rng.integers(0, cfg["vocab_size"], size=(6, 64))
+    q[[0, 1, 3, 4, 6, 7]] = rng.integers(0, cfg["vocab_size"], size=(6, 160))
     c, lc = _greedy(eng, q, 8)
     assert np.array_equal(c[:, 2], a[:, 2]) and np.array_equal(lc[2], la[2])   # other neighbours
+
+
+def test_short_prefill_on_the_streaming_kernel(big):
+    """A prompt of <= 128 rows goes through the decode steps' weight-streaming kernel (one read of W, split K) instead of
+    the tile GEMM: same model, another summation order -- the logits agree to rounding noise with the tile-GEMM route
+    (option short_prefill_skinny = 0), and it is the faster route at that size."""
+    import time
+
+    eng, cfg = big
+    rng = np.random.default_rng(8)
+    p = rng.integers(0, cfg["vocab_size"], size=(1, 96)).astype(np.int32)
+    fast, lf = _greedy(eng, p, 4)
+    tile, lt = _greedy(eng, p, 4, short_prefill_skinny=0)
+    _same_tokens_up_to_near_ties(fast, tile, lf, lt)
+
+    def timed(**opts):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        best = 1e9
+        for _ in range(3):
+            kv = eng.new_kv(1, capacity=128, kv_dtype="model")
+            eng.sync(); t0 = time.perf_counter()
+            eng.forward(p, kv)
+            best = min(best, time.perf_counter() - t0)
+            kv.close()
+        eng.set_option("short_prefill_skinny", 1)
+        return best
+
+    t_fast, t_tile = timed(), timed(short_prefill_skinny=0)
+    print(f"96-token prefill: streaming kernel {t_fast * 1e3:.2f} ms, tile GEMM {t_tile * 1e3:.2f} ms")
+    assert t_fast < t_tile
 
 
 def test_prefill_and_stepwise_decode_reach_the_same_state(big):
