@@ -29,6 +29,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef MI_GEMM_VARIANT
+#define MI_GEMM_VARIANT 0       // A/B experiments (tools/debug/gemm_ab.py); 0 = the shipped kernel
+#endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDA = 72;   // LDS row stride in elements (144 B)
 
@@ -335,9 +338,15 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
         if (it == 3) b_frags(b_img(cur), 1, bf[1]);
         if (it == SYNC_AT) b_frags(b_img(cur ^ 1), 0, bf[0]);     // (bf[0] is dead since item 7)
       }
+#if MI_GEMM_VARIANT == 1
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[it & 7][nt] = mfma16<AT>(af[it % AFR], BD ? bc[it >> 3][nt] : bf[it >> 3][nt], acc[it & 7][nt]);
+#if MI_GEMM_VARIANT == 1
+      __builtin_amdgcn_s_setprio(0);
+#endif
       // the order is imposed on hipcc's scheduler (sched_group_barrier: 0x100 = LDS read, 0x008 = MFMA); left alone
       // it bunches the fragment reads and waits for them in front of single MFMAs
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
