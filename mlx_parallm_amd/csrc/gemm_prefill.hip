@@ -410,6 +410,170 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same 256 x 256 x 64 tile on v_mfma_f32_32x32x16: per wave and K step 32 MFMAs of 32 cycles instead of 64 of 16.
+// Why: a 16x16x32 MFMA leaves 8 of its 16 cycles for other instructions to issue, the loop has ~135 of them per 64 MFMAs
+// (24 LDS reads, 8 + 8 staging loads / stores, ~45 address VALU, the waits) -- more than one wave's MFMA shadow holds;
+// a 32x32x16 MFMA leaves 24 of 32 cycles, i.e. 6 issue slots per MFMA and ~190 per K step.  Same staging, same LDS images
+// (the A fragment of 32 rows x 16 k reads rows at the padded 144-byte stride: the 16 lanes of a read group hit 16
+// distinct 16-byte slots; the B fragment of 32 W rows x 16 k is two 256-byte runs of the tile-major image, 2 KiB apart:
+// conflict-free), same barrier placement.  Item (ks16, mt) = 2 MFMAs (the wave's two 32-column N tiles); SwiGLU: N tile 0
+// is the gate tile, N tile 1 the matching up tile.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T>
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (std::is_same<T, bf16>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <typename AT, bool SWIGLU>
+__global__ __launch_bounds__(512) void gemm_tile256_m32_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;              // 2 x 4 waves
+  const int c32 = lane & 31, h2 = lane >> 5;
+  const int bm = blockIdx.x, bn = blockIdx.y;
+  const int m0 = bm * BM2;
+  const int nk = p.K / BK, nkw = p.kw / BK;
+  const AT* x = (const AT*)p.x;
+  const int ntiles_w = p.N / 16;
+  auto a_img = [&](int buf) { return (AT*)(smem2 + (size_t)buf * A2_BYTES); };
+  auto b_img = [&](int buf) { return smem2 + 2 * (size_t)A2_BYTES + (size_t)buf * B2_BYTES; };
+  auto w_tile_of = [&](int s) -> int {
+    int t;
+    if constexpr (!SWIGLU) t = (bn * BN2) / 16 + s;
+    else t = (bn * 128 + (s >> 2) * 32 + (s & 1) * 16 + ((s >> 1) & 1) * p.pair_offset) / 16;
+    return min(t, ntiles_w - 1);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 areg[4], breg[4];
+  const AT* arow[4];
+  const char* brow[4];
+  bool aok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
+    aok[i] = m0 + row < p.M;
+    arow[i] = x + (size_t)min(m0 + row, p.M - 1) * p.ldx + kq * 8;
+    const int s = c >> 7, kb = (c >> 6) & 1, l = c & 63;
+    brow[i] = (const char*)p.w + ((size_t)w_tile_of(s) * (p.kw / 32) + (size_t)kb) * 1024 + l * 16;
+  }
+  auto load_ab = [&](int ks) {
+    const int ka = (ks * BK) % p.ka;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[i] = *(const u32x4*)(arow[i] + ka);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) breg[i] = *(const u32x4*)(brow[i] + (size_t)(ks % nkw) * 2048);
+  };
+  auto store_ab = [&](int buf) {
+    AT* A = a_img(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i, row = c >> 3, kq = c & 7;
+      *(u32x4*)&A[row * LDA + kq * 8] = aok[i] ? areg[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+    unsigned char* B = b_img(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(B + (size_t)(tid + 512 * i) * 16) = breg[i];
+  };
+
+  // item it = (ks16 = it >> 2, mt = it & 3): A fragment of rows wm*128 + 32 mt + c32, k = 16 ks16 + 8 h2
+  u32x4 af[AFR], bf[4][2];
+  auto a_frag = [&](const AT* A, int it) {
+    return *(const u32x4*)&A[(wm * 128 + (it & 3) * 32 + c32) * LDA + (it >> 2) * 16 + h2 * 8];
+  };
+  auto b_frags = [&](const unsigned char* B, int ks16, u32x4 (&dst)[2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int slot = wn * 4 + nt * 2 + (c32 >> 4);
+      dst[nt] = *(const u32x4*)(B + (size_t)(((slot * 2 + (ks16 >> 1)) * 64) + (2 * (ks16 & 1) + h2) * 16 + (c32 & 15)) * 16);
+    }
+  };
+  auto step = [&](int ks) {
+    const int cur = ks & 1;
+    load_ab(min(ks + 1, nk - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const AT* A = a_img(cur);
+    const AT* An = a_img(cur ^ 1);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (it == SYNC_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int nx = it + AFR - 1;
+      af[nx % AFR] = nx < 16 ? a_frag(A, nx) : a_frag(An, nx - 16);
+      if (it == 1) b_frags(b_img(cur), 1, bf[1]);
+      if (it == 5) b_frags(b_img(cur), 2, bf[2]);
+      if (it == 9) b_frags(b_img(cur), 3, bf[3]);
+      if (it == SYNC_AT) b_frags(b_img(cur ^ 1), 0, bf[0]);        // (bf[0] is dead since item 3)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[it & 3][nt] = mfma32<AT>(af[it % AFR], bf[it >> 2][nt], acc[it & 3][nt]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (it == 1 || it == 5 || it == 9 || it == SYNC_AT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (it == STORE_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        store_ab(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  load_ab(0);
+  store_ab(0);
+  __syncthreads();
+  b_frags(b_img(0), 0, bf[0]);
+#pragma unroll
+  for (int i = 0; i < AFR - 1; ++i) af[i] = a_frag(a_img(0), i);
+  for (int ks = 0; ks < nk; ++ks) step(ks);
+
+  // ---- epilogue: lane (c32, h2), register r holds C[m = (r & 3) + 8 (r >> 2) + 4 h2][n = c32] of every 32 x 32 tile
+  AT* out = (AT*)p.out;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+      if (m >= p.M) continue;
+      if constexpr (SWIGLU) {
+        const int n = bn * 128 + wn * 32 + c32;
+        if (n >= p.pair_offset) continue;
+        if (p.out32) { epi32_swiglu(p, m, n, acc[mt][0][r], acc[mt][1][r]); continue; }
+        const float gt = (float)(AT)acc[mt][0][r], up = (float)(AT)acc[mt][1][r];
+        const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+        const float sl = (float)(AT)(gt * sig);
+        out[(size_t)m * p.ldo + n] = (AT)(sl * up);
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int n = bn * BN2 + wn * 64 + nt * 32 + c32;
+          if (n >= p.N) continue;
+          if (p.out32) { epi32_plain(p, m, n, acc[mt][nt][r]); continue; }
+          const float y = (float)(AT)acc[mt][nt][r];
+          if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
+          else {
+            AT* hh = (AT*)p.resid;
+            hh[(size_t)m * p.ldo + n] = (AT)((float)hh[(size_t)m * p.ldo + n] + y);
+          }
+        }
+      }
+    }
+}
+
 // out[row][:] = w * cast_T(x32 * rsqrt(mean(x32^2) + eps))   (nn.RMSNorm); one wave per row
 template <typename AT>
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const AT* x, int ldx, const AT* w, AT* out, int ldo,
@@ -657,8 +821,12 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
   if (rows >= 256 && !small_only && blocks256 >= 192) {  // both operands through LDS (gemm_tile256_kernel)
     const int bn = sw ? 128 : BN2;
     const dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
+    static const bool m32 = getenv("MI_GEMM_M32") != nullptr;               // A/B: the 32x32x16 form of the tile
 #define GO256(T, S) do { \
-      if (b_in_lds) { auto k = gemm_tile256_kernel<T, S, false>; \
+      if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
+        hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } \
+      else if (b_in_lds) { auto k = gemm_tile256_kernel<T, S, false>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
         hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } \
       else { auto k = gemm_tile256_kernel<T, S, true>; \
