@@ -172,8 +172,8 @@ def parse_args(argv=None):
                          "the same pass over the weights (mi_step_enqueue_mixed, block-paged KV), timed next to the unfused "
                          "schedule (decode step, then the chunk on its own)")
     ap.add_argument("--chunk", type=int, default=0,
-                    help="--mode mixed: prompt tokens ingested per step; 0 = what the live rows leave of the 128 rows (int4: 96) "
-                         "that the weight-streaming kernels serve with one read of W")
+                    help="--mode mixed: prompt tokens ingested per step; 0 = what the live rows leave of 256 rows per step (int4: "
+                         "96, the row limit of its weight-streaming kernel)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-process protocol without an engine (launch, rendezvous, bucketed weight "
                          "broadcast, barrier / max-over-ranks timing) -- the only mode that runs without a GPU; "
@@ -390,7 +390,7 @@ def main():
 
     if args.mode == "mixed":
         if args.chunk <= 0:
-            args.chunk = max(16, (96 if quant_bits == 4 else 128) - (B - 1) - 1)
+            args.chunk = max(16, (96 if quant_bits == 4 else 256) - (B - 1) - 1)
         cap = ctx + K + W + 2 * args.chunk + 128
     engine = Engine(cfg, device=local_rank, max_positions=max(cap, 2048), act_dtype="bfloat16")
     for kv_ in args.opt:
@@ -472,9 +472,12 @@ def main():
         ms_per_step = leg["elapsed"] / K * 1e3
         avg_ms = leg["total_ms"] / max(leg["n_launch"], 1)
         achieved = kern_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # prefill: algorithmic flops = 2 W T + NL 2 S^2 Hq D per sequence (causal), whatever the implementation
+        # spends on top (the float32 leg multiplies the exact three-way split of x: 3 x the MFMA work for the same flops)
+        pf_flops = B * (2.0 * n_params * ctx + cfg["num_hidden_layers"] * 2.0 * ctx * ctx * nh * D)
         return dict(ms_per_step=ms_per_step, value=world * B * K / leg["elapsed"], step_bytes=step_bytes,
                     kern_bytes=kern_bytes, avg_ms=avg_ms, achieved=achieved,
-                    prefill=world * B * ctx / leg["t_prefill"])
+                    prefill=world * B * ctx / leg["t_prefill"], pf_tflops=pf_flops / leg["t_prefill"] / 1e12, pf_flops=pf_flops)
 
     def pmc_traffic(kv_dtype):
         """HBM bytes per launch of the dominant kernel.  NOT measured in this run: read from the committed PMC passes
@@ -529,6 +532,9 @@ def main():
             "step_hbm_frac": round(hn["step_bytes"] / (hn["ms_per_step"] * 1e-3) / 8e12, 4),
             "step_hbm_frac_of_achievable": round(hn["step_bytes"] / (hn["ms_per_step"] * 1e-3) / 6.29e12, 4),
             "prefill_tokens_per_sec": round(hn["prefill"], 1),
+            "prefill_roofline": {"bound": "mfma", "achieved": round(hn["pf_tflops"], 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": round(hn["pf_tflops"] / 2500.0, 4), "flops_per_gpu": hn["pf_flops"],
+                                 "what": "whole prefill call (B x context tokens, all kernels, host-timed) against the dense bf16 MFMA peak"},
             "load_seconds": round(t_load, 2),
             "ranks_seen": ranks_seen,
         }
@@ -541,6 +547,7 @@ def main():
                            if other_mode == "float32" else ""),
                 "value": round(on["value"], 2), "unit": "tokens/s", "ms_per_step": round(on["ms_per_step"], 4),
                 "prefill_tokens_per_sec": round(on["prefill"], 1),
+                "prefill_mfma_frac": round(on["pf_tflops"] / 2500.0, 4),
                 "step_bytes": int(on["step_bytes"]),
                 "step_hbm_frac": round(on["step_bytes"] / (on["ms_per_step"] * 1e-3) / 8e12, 4),
                 "roofline": dict(roofline_of(on, other_mode), launches=other["n_launch"]),

@@ -111,7 +111,7 @@ struct mi_engine {
   // leaves the rows' sums of squares, the normalised linear behind it uses them instead of an rmsnorm launch
   int opt_norm_handover = 0;    // measured neutral (int4 / int8 +-1 %, Qwen3-14B int4 -3.6 %): off by default
   int opt_defer_norm = 1;       // float32 activations: RMSNorm row scale applied in the split-K kernel's epilogue (no norm launch)
-  int opt_short_prefill_skinny = 1;   // prefill calls of <= 128 rows in all on the weight-streaming kernel instead of the tile GEMM
+  int opt_short_prefill_skinny = 1;   // short prefill / mixed calls on the weight-streaming kernel instead of the tile GEMM (gemv_rows)
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
   bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0;
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
@@ -123,6 +123,7 @@ struct mi_engine {
   int last_n = 0;                        // rows of the last enqueued step (device-resident token feed)                // value of *d_seam_counter once every enqueued launch has run
   void* xn = nullptr;            // [rows][max(H, I)] normalised activations of the prefill GEMMs
   void* xs = nullptr; size_t xs_cap = 0;   // [rows][3 K] bf16: float32 activations split three ways (float32-KV prefill)
+  void* gk_ws = nullptr; size_t gk_cap = 0;   // float32 partial tiles of the K-split 128 x 128 tile GEMM
 };
 
 struct mi_kv {
@@ -323,7 +324,55 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   c.force_v1 = e->opt_force_v1;
   const bool sq_was_valid = e->sq_valid;      // whatever runs now consumes or invalidates the hand-over
   e->sq_valid = false;
-  if (e->opt_skinny_gemm && (e->cur_L == 1 || (rows <= 128 && e->opt_short_prefill_skinny)) && gemm_skinny_supported(f.W, c, rows)) {
+  // Which kernel for a call that is not a pure decode step (prefill, mixed step)?  Measured on Mistral-7B shapes, one prompt
+  // of L tokens (tools/debug/prefill_sweep.py, ms for the whole call): dense 16-bit weights -- streaming kernel 4.2 / 5.1 /
+  // 6.1 / 6.9 at L = 32 / 64 / 96 / 128 against 5.2 / 5.5 / 5.6 / 5.8 on the K-split 128 x 128 tile: the hand-over is at ~80 rows;
+  // int4 -- 3.0 / 5.0 / 6.9 (L <= 96) against 15.5 on the tile path, which first writes a [hi | lo] 16-bit copy of every
+  // matrix (4 x 54 us per layer): the streaming kernel keeps the call, in two row slabs up to twice its row limit.
+  static const int dense_short = getenv("MI_SHORT_PREFILL_ROWS") ? atoi(getenv("MI_SHORT_PREFILL_ROWS")) : 64;
+  const bool quant = wk_is_quant(f.W.wk);
+  const size_t short_rows = e->opt_short_prefill_skinny ? (quant ? 128 : (size_t)dense_short) : 0;
+  if (e->opt_skinny_gemm && e->cur_L != 1 && quant && e->opt_short_prefill_skinny && rows > 64 && rows <= 256 &&
+      !gemm_skinny_supported(f.W, c, rows)) {
+    // quantised weights, a call just above the streaming kernel's row limit: two slabs of rows, two reads of W
+    const size_t half = (rows + 1) / 2;
+    GemvCall probe = c; probe.pro = PRO_NONE;
+    if (gemm_skinny_supported(f.W, probe, half) && f.W.lora_b[0] == nullptr && f.W.lora_b[1] == nullptr) {
+      Prof pr(e, prof);
+      if (c.pro == PRO_NORM) {
+        MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
+        c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+      }
+      const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
+      for (size_t r = 0; r < rows; r += half) {
+        GemvCall cc = c;
+        cc.M = (int)std::min(half, rows - r);
+        cc.x = x0 + r * (size_t)c.ldx * es_in;
+        if (o0) cc.out = o0 + r * (size_t)c.ldo * es_out;
+        if (r0) cc.resid = r0 + r * (size_t)c.ldo * es_in;
+        const size_t need = gemm_skinny_ws_bytes(f.W, cc, (size_t)cc.M);
+        const int groups = gemm_skinny_groups(f.W, cc, (size_t)cc.M);
+        if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
+          MI_HIP(hipStreamSynchronize(e->stream));
+          if (need > e->sk_ws_cap) {
+            hipFree(e->sk_ws); e->sk_ws = nullptr; e->sk_ws_cap = 0;
+            MI_HIP(hipMalloc(&e->sk_ws, need));
+            e->sk_ws_cap = need;
+          }
+          if (groups > e->sk_ctr_cap) {
+            hipFree(e->sk_ctr); e->sk_ctr = nullptr; e->sk_ctr_cap = 0;
+            const int cap = std::max(groups, 4096);
+            MI_HIP(hipMalloc(&e->sk_ctr, (size_t)cap * sizeof(unsigned)));
+            MI_HIP(hipMemsetAsync(e->sk_ctr, 0, (size_t)cap * sizeof(unsigned), e->stream));
+            e->sk_ctr_cap = cap;
+          }
+        }
+        MI_TRY(launch_gemm_skinny(f.W, cc, (size_t)cc.M, e->stream, e->sk_ws, e->sk_ctr));
+      }
+      return MI_OK;
+    }
+  }
+  if (e->opt_skinny_gemm && (e->cur_L == 1 || rows <= short_rows) && gemm_skinny_supported(f.W, c, rows)) {
     // the decode step of a batch of 9..128 sequences (int4 / int8 weights: any batch up to 128): W is streamed once, K split over workgroups (gemm_skinny.hip).
     // Also a prefill of up to 128 rows in all (a short prompt, a few short prompts): at that size the op is a weight
     // stream, not a GEMM -- measured on Mistral-7B bf16, one prompt of 64 tokens: 13.0 ms through the 128 x 128 tile GEMM
@@ -403,7 +452,11 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       }
       scratch = e->deq_scratch;
     }
-    MI_TRY(launch_gemm_prefill(f.W, c, rows, e->stream, scratch));
+    if (rows < 2048 && e->gk_ws == nullptr) {     // K-split partial tiles of the 128 x 128 GEMM (prompts of a few hundred rows)
+      e->gk_cap = (size_t)128 << 20;
+      if (hipMalloc(&e->gk_ws, e->gk_cap) != hipSuccess) { e->gk_ws = nullptr; e->gk_cap = 0; }
+    }
+    MI_TRY(launch_gemm_prefill(f.W, c, rows, e->stream, scratch, rows < 2048 ? e->gk_ws : nullptr, e->gk_cap));
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {   // y = T(y + T(scale (x A) B)) on the adapted columns
       c.M = (int)rows;
       MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
@@ -775,10 +828,9 @@ int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* l
       return fail(MI_ERR_INVALID, "mixed step: KV capacity / max_positions exceeded (call mi_kv_reserve)");
     tok0[i] = R; R += (size_t)lens[i];
   }
-  // Up to 128 tokens in all (decode rows + chunks) the linears stay the decode step's weight-streaming kernels: ONE read
-  // of W for every row (gemm_skinny.hip serves 1..128 rows; a 256-row tile GEMM would leave most CUs idle at this
-  // size and cost more than the weights' stream).  Larger steps take the prefill path's tile GEMM.
-  e->cur_L = R <= 128 ? 1 : 2;
+  // Only decode rows: the decode step's kernels.  Otherwise the call is routed like a prefill of R rows (gemv_rows: the
+  // weight-streaming kernel for short calls, the K-split 128 x 128 tile for a few hundred rows, plain tiles above).
+  e->cur_L = R == (size_t)nd ? 1 : 2;
   e->sq_valid = false;
   if (!kv->d_rows) MI_HIP(hipMalloc(&kv->d_rows, kv->B * sizeof(int32_t)));
   MI_HIP(hipMemcpyAsync(kv->d_rows, rows, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -992,7 +1044,7 @@ void mi_engine_destroy(mi_engine* e) {
     hipFree(l.in_norm); hipFree(l.post_norm); hipFree(l.q_norm); hipFree(l.k_norm);
     hipFree(l.in_norm32); hipFree(l.post_norm32); hipFree(l.q_norm32); hipFree(l.k_norm32);
   }
-  hipFree(e->final_norm32); hipFree(e->xn); hipFree(e->xs);
+  hipFree(e->final_norm32); hipFree(e->xn); hipFree(e->xs); hipFree(e->gk_ws);
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced); hipFree(e->d_gather);

@@ -15,6 +15,7 @@
 //     The next step's 8 fragments are prefetched into a second register set.
 //   * SwiGLU: a wave's four N tiles are two gate tiles and the two matching up tiles, so
 //     silu(gate) * up happens in registers.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,6 +54,10 @@ struct GemmParams {
                                     // every (x part, W part) pair once.
   int out32;                        // outputs / residual stream are float32 (PagedKVCache mode), no 16-bit rounding
   int epi; void* out; int ldo; void* resid; int pair_offset;
+  // 128 x 128 tile only: K split over gridDim.z workgroups when the (M, N) grid alone leaves most CUs idle (a prompt of a
+  // few hundred tokens against N = 4096: 32 x 2..8 blocks); slice z leaves its float32 partial tile in ws[z][M][N] and
+  // splitk_epilogue_kernel adds the slices in order and applies the epilogue
+  int ksplit; float* ws;
 };
 
 // the epilogues in float32 storage (PagedKVCache mode after layer 0: every op produces a float32 array)
@@ -77,7 +82,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
   // W tiles, which then stay in the XCD's L2 instead of being re-fetched per block
   const int bm = blockIdx.x, bn = blockIdx.y;
   const int m0 = bm * BM;
-  const int nk = p.K / BK, nkw = p.kw / BK;
+  const int nk_all = p.K / BK, nkw = p.kw / BK;
+  const int ks0 = (int)(((long)blockIdx.z * nk_all) / p.ksplit), ks1 = (int)(((long)(blockIdx.z + 1) * nk_all) / p.ksplit);
+  const int nk = ks1;                               // (the loop runs over [ks0, ks1); "nk" bounds the prefetches)
   const AT* x = (const AT*)p.x;
 
   // W tiles (16 rows each) of this wave's four N tiles
@@ -130,16 +137,16 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
       }
   };
 
-  load_a(0);
-  load_b(0, 0);
-  if (nk > 1) load_b(1, 1);
+  load_a(ks0);
+  load_b(0, ks0);
+  if (ks0 + 1 < nk) load_b(1, ks0 + 1);
   store_a(0);
   __syncthreads();
 
   // the K loop is unrolled by 3 so that the register set of each step is a compile-time index
   auto step = [&](int ks, auto set_tag) {
     constexpr int SET = decltype(set_tag)::value;
-    const int cur = ks & 1;
+    const int cur = (ks - ks0) & 1;
     load_a(min(ks + 1, nk - 1));
     load_b((SET + 2) % 3, min(ks + 2, nk - 1));
     __builtin_amdgcn_sched_barrier(0);           // the loads stay ahead of this step's MFMAs
@@ -158,10 +165,29 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
       __syncthreads();
     }
   };
-  for (int ks = 0; ks < nk; ks += 3) {
+  for (int ks = ks0; ks < nk; ks += 3) {
     step(ks, std::integral_constant<int, 0>{});
     if (ks + 1 < nk) step(ks + 1, std::integral_constant<int, 1>{});
     if (ks + 2 < nk) step(ks + 2, std::integral_constant<int, 2>{});
+  }
+
+  if constexpr (!SWIGLU) {
+    if (p.ksplit > 1) {                            // this K slice's partial tile, float32, for splitk_epilogue_kernel
+      float* wz = p.ws + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + mt * 16 + 4 * g + r;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int n = bn * BN + wn * 64 + nt * 16 + c16;
+            if (n < p.N) wz[(size_t)m * p.N + n] = acc[mt][nt][r];
+          }
+        }
+      return;
+    }
   }
 
   // ---- epilogue: lane (c16, g) holds C[m = 4g + r][n = c16] of every 16 x 16 tile
@@ -198,6 +224,25 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmParams p) {
         }
       }
     }
+}
+
+// the K slices of gemm_tile_kernel, added in slice order, + the epilogue (EPI_STORE / EPI_RESID); 4 columns per thread
+template <typename AT>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total4 = (size_t)p.M * p.N / 4;
+  if (i4 >= total4) return;
+  const size_t e0 = i4 * 4;
+  const int m = (int)(e0 / p.N), n = (int)(e0 % p.N);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.ksplit; ++z) a += *(const f32x4*)(p.ws + (size_t)z * p.M * p.N + e0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (p.out32) { epi32_plain(p, m, n + j, a[j]); continue; }
+    const float y = (float)(AT)a[j];
+    if (p.epi == EPI_STORE) ((AT*)p.out)[(size_t)m * p.ldo + n + j] = (AT)y;
+    else { AT* h = (AT*)p.resid; h[(size_t)m * p.ldo + n + j] = (AT)((float)h[(size_t)m * p.ldo + n + j] + y); }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -795,9 +840,11 @@ int launch_split3_rows(const void* x, int ldx, const void* norm_w, float eps, vo
   return MI_OK;
 }
 
-int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch) {
+int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch, void* splitk_ws,
+                        size_t splitk_cap) {
   if (c.pro != PRO_NONE) return fail(MI_ERR_INVALID, "gemm_prefill: normalise the rows first");
   GemmParams p{};
+  p.ksplit = 1;
   p.x = c.x; p.ldx = c.ldx; p.M = (int)rows; p.w = W.w; p.N = W.N; p.K = W.K; p.ka = W.K; p.kw = W.K;
   if (wk_is_quant(W.wk)) {
     if (scratch == nullptr) return fail(MI_ERR_INVALID, "gemm_prefill: int4 weights need a dequantisation scratch buffer");
@@ -838,7 +885,19 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     MI_HIP(hipGetLastError());
     return MI_OK;
   }
-  const dim3 grid(((int)rows + BM - 1) / BM, (ncols + (sw ? 64 : BN) - 1) / (sw ? 64 : BN)), block(256);
+  dim3 grid(((int)rows + BM - 1) / BM, (ncols + (sw ? 64 : BN) - 1) / (sw ? 64 : BN)), block(256);
+  // too few (M, N) blocks for 256 CUs: split K (plain / residual epilogues; W.N % 4 == 0 for the reduce kernel)
+  static const bool no_splitk = getenv("MI_GEMM_NO_SPLITK") != nullptr;
+  const long blocks = (long)grid.x * grid.y;
+  // ~512 workgroups of 256 threads in all (two per CU): measured against a target of 256 -- 10.5 vs 11.6 ms at 384 rows,
+  // 20.0 vs 21.4 at 768, 21.4 vs 22.4 at 1024 (Mistral-7B bf16, whole prefill call)
+  static const int target = getenv("MI_GEMM_SPLITK_TARGET") ? atoi(getenv("MI_GEMM_SPLITK_TARGET")) : 512;   // A/B
+  if (!sw && !no_splitk && splitk_ws != nullptr && blocks < target && W.N % 4 == 0) {
+    int ks = (int)std::min<long>(8, std::max<long>(1, target / blocks));
+    ks = std::min(ks, (p.K / BK) / 8);                       // at least 8 K steps per slice
+    while (ks > 1 && (size_t)ks * rows * W.N * sizeof(float) > splitk_cap) --ks;
+    if (ks > 1) { p.ksplit = ks; p.ws = (float*)splitk_ws; grid.z = ks; }
+  }
   if (c.act == MI_BF16 || x32) {
     if (sw) hipLaunchKernelGGL((gemm_tile_kernel<bf16, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_tile_kernel<bf16, false>), grid, block, 0, st, p);
@@ -847,6 +906,13 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     else hipLaunchKernelGGL((gemm_tile_kernel<f16, false>), grid, block, 0, st, p);
   }
   MI_HIP(hipGetLastError());
+  if (p.ksplit > 1) {
+    const size_t total4 = rows * (size_t)W.N / 4;
+    const dim3 rg((unsigned)((total4 + 255) / 256));
+    if (c.act == MI_F16) hipLaunchKernelGGL(splitk_epilogue_kernel<f16>, rg, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel<bf16>, rg, dim3(256), 0, st, p);
+    MI_HIP(hipGetLastError());
+  }
   return MI_OK;
 }
 

@@ -72,7 +72,10 @@ int gemv_pair_grid();
 
 // prefill (many rows): MFMA tile GEMM + row-wise RMSNorm (gemm_prefill.hip)
 bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows);
-int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch = nullptr);
+// splitk_ws / splitk_cap: float32 workspace for the K-split form of the 128 x 128 tile (few hundred rows against a narrow
+// matrix); null = never split
+int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* scratch = nullptr,
+                        void* splitk_ws = nullptr, size_t splitk_cap = 0);
 // float32 activations (PagedKVCache mode) in front of launch_gemm_prefill: rows of [hi | mid | lo] bf16, 3 K wide, with the
 // RMSNorm (norm_w = float32 weights, or null) applied first; then call launch_gemm_prefill with c.x = out, c.ldx = 3 K
 size_t split3_bytes(size_t rows, int K);

@@ -16,6 +16,10 @@ if q:
     cfg["quantization"] = {"group_size": 64, "bits": q}
 eng = Engine(cfg, device=0, max_positions=4096, act_dtype="bfloat16")
 bench.load_synthetic(eng, cfg, 0, q, 0, 1, None)
+for kv_ in sys.argv[2:]:                                   # engine options key=value
+    k_, v_ = kv_.split("=")
+    eng.set_option(k_, int(v_))
+    print("option", k_, v_)
 rng = np.random.default_rng(0)
 g = SampleArgs(temp=0.0)
 for L in (32, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 2048):
