@@ -372,7 +372,11 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       return MI_OK;
     }
   }
-  if (e->opt_skinny_gemm && (e->cur_L == 1 || rows <= short_rows) && gemm_skinny_supported(f.W, c, rows)) {
+  // decode steps: the streaming kernel up to 96 rows for dense weights -- above that the K-split tile GEMM is ahead
+  // (Mistral-7B bf16, KV 512: 96 rows 7.18 vs 7.14 ms / step, 128 rows 8.71 vs 7.96)
+  static const int decode_max_env = getenv("MI_SKINNY_DECODE_MAX") ? atoi(getenv("MI_SKINNY_DECODE_MAX")) : 0;   // A/B
+  const size_t decode_max = decode_max_env > 0 ? (size_t)decode_max_env : (quant ? 128 : 96);
+  if (e->opt_skinny_gemm && ((e->cur_L == 1 && rows <= decode_max) || rows <= short_rows) && gemm_skinny_supported(f.W, c, rows)) {
     // the decode step of a batch of 9..128 sequences (int4 / int8 weights: any batch up to 128): W is streamed once, K split over workgroups (gemm_skinny.hip).
     // Also a prefill of up to 128 rows in all (a short prompt, a few short prompts): at that size the op is a weight
     // stream, not a GEMM -- measured on Mistral-7B bf16, one prompt of 64 tokens: 13.0 ms through the 128 x 128 tile GEMM
