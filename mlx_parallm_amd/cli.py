@@ -47,7 +47,12 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", type=int, default=d.device, help="HIP device index.")
     p.add_argument("--devices", default=None, help="Comma-separated HIP device indices: one model replica per GPU, "
                    "requests spread over them (implies --scheduler continuous).")
-    p.add_argument("--version", action="version", version="0.1.0")
+    p.add_argument("--chunk-tokens", type=int, default=d.chunk_tokens,
+                   help="continuous scheduler: prompt tokens per step that enter the cache inside the live rows' decode steps (0: off).")
+    p.add_argument("--kv-blocks", type=int, default=None, help="continuous scheduler: 64-token blocks of the paged KV arena "
+                   "(default: every slot at full length, capped at 80 %% of the free device memory).")
+    p.add_argument("--no-prefix-cache", action="store_true", help="continuous scheduler: do not reuse the KV blocks of a common prompt prefix.")
+    p.add_argument("--version", action="version", version="0.2.0")
     return p
 
 
@@ -58,7 +63,8 @@ def parse_args(argv: Optional[Sequence[str]] = None) -> ServerConfig:
                         request_timeout_seconds=ns.request_timeout_seconds,
                         max_concurrent_streams=ns.max_concurrent_streams, scheduler=ns.scheduler,
                         diverse_mode=bool(ns.diverse_mode), max_context_length=ns.max_context_length, device=ns.device,
-                        devices=[int(x) for x in ns.devices.split(",")] if ns.devices else None)
+                        devices=[int(x) for x in ns.devices.split(",")] if ns.devices else None,
+                        chunk_tokens=ns.chunk_tokens, kv_blocks=ns.kv_blocks, prefix_cache=not ns.no_prefix_cache)
 
 
 def cli_runner(argv: Optional[Sequence[str]] = None) -> None:

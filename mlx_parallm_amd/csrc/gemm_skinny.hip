@@ -95,7 +95,10 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   using XT = typename std::conditional<X32, float, AT>::type;
   constexpr int NIMG = X32 ? 3 : 1;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
-  constexpr int UK = (Q4 ? 4 : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
+#ifndef MI_SK_Q4_UK_SMALL
+#define MI_SK_Q4_UK_SMALL 4
+#endif
+  constexpr int UK = (Q4 ? (MT <= 2 ? MI_SK_Q4_UK_SMALL : 4) : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
   constexpr int UPC = Q4 ? 2 : Q8 ? 4 : 8;  // loads per chunk (a load covers 128 / 64 / 32 k)
   constexpr int CPI = UK > UPC ? UK / UPC : 1;   // chunks per trip of the loop body (the slot ring has UK entries)
   constexpr int UB = Q4 ? 1152 : Q8 ? 1088 : 1024;   // bytes of one tile-major block

@@ -89,6 +89,11 @@ class ServerConfig:
     stream_batch_timeout: float = 0.02            # main.py:85
     device: int = 0
     devices: Optional[List[int]] = None           # more than one: a model replica per GPU (continuous scheduler)
+    # continuous scheduler (this build): prompt tokens per step that ride in the live rows' decode steps (0 = prefill each
+    # prompt alone), blocks of the paged KV arena (None = from the free device memory), prefix-KV reuse
+    chunk_tokens: int = 256
+    kv_blocks: Optional[int] = None
+    prefix_cache: bool = True
 
     @classmethod
     def from_env(cls, base: Optional["ServerConfig"] = None) -> "ServerConfig":
@@ -772,7 +777,9 @@ def create_app(config: Optional[ServerConfig] = None, *, model=None, tokenizer=N
             from .scheduler import ReplicaPool
 
             state.scheduler = ReplicaPool([rec.model_instance] + state.extra_replicas, rec.tokenizer_instance,
-                                          max_slots=config.max_batch_size, metrics=state.metrics)
+                                          max_slots=config.max_batch_size, metrics=state.metrics,
+                                          chunk_tokens=config.chunk_tokens, kv_blocks=config.kv_blocks,
+                                          prefix_cache=config.prefix_cache)
             state.scheduler.start()
             state.tasks = []
         else:

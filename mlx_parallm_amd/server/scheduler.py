@@ -77,6 +77,8 @@ class ContinuousScheduler:
         eng = model.engine
         self.paged = bool(paged) and hasattr(eng, "new_paged_kv")
         if self.paged:
+            if kv_blocks is None:
+                kv_blocks = self._default_blocks(eng, block_tokens, kv_dtype or DEFAULT_KV_DTYPE)
             self.kv = eng.new_paged_kv(self.max_slots, block_tokens=block_tokens, n_blocks=kv_blocks,
                                        max_tokens_per_row=eng.max_positions, kv_dtype=kv_dtype or DEFAULT_KV_DTYPE)
         else:
@@ -107,6 +109,38 @@ class ContinuousScheduler:
         self.step_rows = int(step_rows)
         self.mixed_steps = 0               # steps that carried prompt chunks next to decode rows
         self.chunks = 0
+
+    def _default_blocks(self, eng, block_tokens: int, kv_dtype: str) -> int:
+        """Arena size: every slot at full length if that fits in 80 % of the device memory that is free now, else what
+        fits (requests then wait for blocks instead of for slots: _fits)."""
+        per_row = (eng.max_positions + block_tokens - 1) // block_tokens
+        full = self.max_slots * per_row + 1
+        try:
+            import torch
+
+            free, _total = torch.cuda.mem_get_info(eng.device)
+            d = eng.desc
+            esz = 4 if kv_dtype == "float32" else (4 if eng.act_dtype == "float32" else 2)
+            block_bytes = 2 * d.num_layers * d.num_kv_heads * block_tokens * d.head_dim * esz
+            return int(max(2 * per_row + 1, min(full, int(0.8 * free) // block_bytes)))
+        except Exception:            # (no torch / no device query: the full size, and the allocation says if it is too much)
+            return full
+
+    def _fits(self, seq: "Sequence") -> bool:
+        """Admission control on the block arena: the prompt and everything the sequence may generate must find blocks now
+        (free ones, or published prefix blocks nobody is using) -- a step that runs out of blocks would fail every live row."""
+        if not self.paged:
+            return True
+        st = self.kv.stats()
+        bt = self.kv.block_tokens
+        need = (len(seq.prompt) + seq.max_tokens + bt - 1) // bt
+        growth = 0                   # blocks the live sequences may still ask for
+        offs = self.kv.offsets
+        for s in self.slots:
+            if s is not None and not s.finished:
+                end = len(s.prompt) + s.max_tokens
+                growth += max(0, (end + bt - 1) // bt - (offs[s.slot] + bt - 1) // bt)
+        return need + growth <= st["free_blocks"] + st["cached_blocks"]
 
     # ------------------------------------------------------------------ client side (any thread)
     def submit(self, prompt_ids, max_tokens: int, temp: float, top_p: float, sink: Sink) -> Sequence:
@@ -286,6 +320,8 @@ class ContinuousScheduler:
                 self._emit(s, None, "cancelled")
             if s is not None and s.finished:
                 self.slots[i] = None
+                if self.paged:                 # the row's blocks go back to the arena now (waiting requests count on them)
+                    self.kv.reset_row(i)
 
     def _drop_cancelled_pending(self) -> None:
         with self.cv:
@@ -334,7 +370,17 @@ class ContinuousScheduler:
                     while True:
                         with self.cv:
                             free = [i for i, s in enumerate(self.slots) if s is None]
-                            seq = self.pending.popleft() if (free and self.pending) else None
+                            seq = self.pending[0] if (free and self.pending) else None
+                            if seq is not None and not self._fits(seq):
+                                if any(s is not None and not s.finished for s in self.slots):
+                                    seq = None               # wait for blocks: a live sequence will give some back
+                                else:
+                                    self.pending.popleft()   # nothing is running and it still does not fit: it never will
+                                    seq.finished = "error"
+                                    self._emit(seq, "\n\nError during generation: prompt + max_tokens exceed the KV arena", "error")
+                                    continue
+                            elif seq is not None:
+                                self.pending.popleft()
                         if seq is None:
                             break
                         drain()

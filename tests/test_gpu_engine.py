@@ -737,3 +737,49 @@ def test_prefix_reuse_on_the_paged_cache(tiny_dirs, name):
     assert kv.stats()["cached_blocks"] == 0
     kv.close()
     eng.close()
+
+
+def test_scheduler_waits_for_kv_blocks_instead_of_failing_live_rows(tiny_dirs):
+    """The continuous scheduler on a deliberately small block arena (7 usable blocks of 16 tokens, 2 slots): the second
+    request finds a free slot but not the blocks its prompt + max_tokens may need, so it waits until the first one
+    finishes -- both then equal their solo oracle runs; a request that can never fit is refused with an error, nothing
+    else is disturbed; prompts enter through chunked mixed steps and the second prompt reuses the first one's prefix block."""
+    import threading
+
+    from mlx_parallm_amd.server.scheduler import ContinuousScheduler
+
+    d, cfg = tiny_dirs["llama_f32"]
+    model, tok = utils.load(d)
+    ref = ref_generate.load(d, max_pos=512)
+    sched = ContinuousScheduler(model, tok, max_slots=2, kv_dtype="model", chunk_tokens=16, block_tokens=16, kv_blocks=8)
+    sched.start()
+    done, ev = {}, threading.Event()
+
+    def sink(name):
+        def f(seq, delta, reason):
+            if reason is not None:
+                done[name] = (list(seq.generated), reason)
+                if len(done) == 3:
+                    ev.set()
+        return f
+
+    common = list(range(40, 60))                            # 20 shared prompt tokens: one full 16-token block
+    pa, pb = common + [7, 8, 9], common + [11, 12]
+    sched.submit(pa, 50, 0.0, 1.0, sink("a"))               # 23 + 50 tokens -> 5 blocks
+    sched.submit(pb, 50, 0.0, 1.0, sink("b"))               # 22 + 50 -> 5 blocks: must wait for a's blocks
+    sched.submit(list(range(3, 100)), 400, 0.0, 1.0, sink("huge"))   # 497 tokens -> 32 blocks: never fits
+    assert ev.wait(timeout=120)
+    stats = sched.kv.stats()
+    sched.stop()
+    assert done["huge"][1] == "error" and done["huge"][0] == []
+    eos = tok.eos_token_id
+    for name, p in (("a", pa), ("b", pb)):
+        want = []
+        for _, (t, _p) in zip(range(50), ref_generate.generate_step(np.asarray(p)[None], ref, paged=False)):
+            if int(t[0, 0]) == eos:
+                break
+            want.append(int(t[0, 0]))
+        assert done[name][0] == want, name
+    assert sched.max_rows_seen == 1                          # never both at once: the arena, not the slots, was the limit
+    assert sched.prefix_hit_tokens == 16 and stats["evictions"] >= 0
+    model.engine.close()
