@@ -227,8 +227,9 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *   "decode_attention_mfma"   0: the VALU form of the fused decode attention also for 16-bit caches (default 1)
  *   "skinny_gemm"             0: decode steps of 9..128 rows (int4 / int8 weights: of any size) through <= 16-row
  *                             launches of the M <= 16 kernels instead of the split-K streaming GEMM (default 1)
- *   "norm_handover"           1: RMSNorm statistics handed from the residual epilogue of one split-K launch to the
- *                             staging of the next instead of an rmsnorm launch (default 0: measured neutral)
+ *   "norm_handover"           0: decode steps of <= 16 rows through the split-K kernel run the RMSNorm as its own launch
+ *                             instead of handing its row statistics from the residual epilogue of one launch to the
+ *                             staging of the next (default 1)
  *   "defer_norm"              0: float32-activation (PagedKVCache mode) decode steps run the RMSNorm as its own launch
  *                             instead of applying its row scale in the epilogue of the linear behind it (default 1)
  *   "short_prefill_skinny"    0: prefill calls of <= 128 rows in all through the tile GEMM like longer ones (default 1: the

@@ -30,7 +30,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "gemv_phase.h"
@@ -43,6 +45,7 @@ using namespace gemv;
 
 constexpr int SK_NW = 8;      // waves (= tiles) per workgroup
 constexpr int SK_KC = 256;    // k per activation chunk
+constexpr int SQ_PARTS_MAX = 64;   // norm hand-over: tile groups of the producing linear (N <= 8192)
 
 // 8 int8 codes (two packed dwords) -> 8 16-bit floats: 0..255 are exact in bf16 and f16
 template <typename T>
@@ -81,7 +84,16 @@ struct SkinnyParams {
   const float* lora_b0; const float* lora_b1;
   int lora_row0_0, lora_n_0, lora_rank_0; float lora_scale_0;
   int lora_row0_1, lora_n_1, lora_rank_1; float lora_scale_1;
+#ifdef MI_SK_TRACE
+  unsigned long long* trace;       // debug build: [workgroup][8] wall-clock stamps of this launch (tools/debug/skinny_trace.py)
+#endif
 };
+
+#ifdef MI_SK_TRACE
+#define SK_STAMP(i) do { if (tid == 0) p.trace[(size_t)(blockIdx.x & 1023) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
 
 // QB: 0 = dense 16-bit weights, 4 / 8 = MLX-affine int4 / int8 codes (group 64)
 // X32: float32 activations (the PagedKVCache mode of a bf16 model; dense, int4 and int8 weights): x is split exactly into three 16-bit
@@ -95,10 +107,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   using XT = typename std::conditional<X32, float, AT>::type;
   constexpr int NIMG = X32 ? 3 : 1;
   constexpr int MB = 16 * MT, NA = SWIGLU ? 2 : 1;
-#ifndef MI_SK_Q4_UK_SMALL
-#define MI_SK_Q4_UK_SMALL 4
-#endif
-  constexpr int UK = (Q4 ? (MT <= 2 ? MI_SK_Q4_UK_SMALL : 4) : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all)
+  constexpr int UK = (Q4 ? 4 : 8) / NA;     // weight loads in flight per wave and stream (8 / 4 per wave in all; int4 with 8 / 16 at <= 32 rows measured 4 / 15 % slower: occupancy)
   constexpr int UPC = Q4 ? 2 : Q8 ? 4 : 8;  // loads per chunk (a load covers 128 / 64 / 32 k)
   constexpr int CPI = UK > UPC ? UK / UPC : 1;   // chunks per trip of the loop body (the slot ring has UK entries)
   constexpr int UB = Q4 ? 1152 : Q8 ? 1088 : 1024;   // bytes of one tile-major block
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // partial sums into rsqrt(mean + eps) and normalises while it stages x -- no launch for the norm, no second pass
   // over x.  (Letting every workgroup compute the statistics itself from x was measured slower than the launch.)
   __shared__ float rs_sh[16];
+  __shared__ float sqp_sh[SK_NW * 16];
   const bool norm = (MT == 1) && p.sq_in != nullptr;
   u32x4 xr[MT], xw[MT], xr2[X32 ? MT : 1], xnw[X32 ? MT : 1], xnw2[X32 ? MT : 1];
   float sqacc[X32 ? MT : 1];
@@ -392,28 +402,58 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // ================= prologue: activations first (older in the vmcnt queue), then the first UK blocks
   unsigned char* cur = smem;
   unsigned char* nxt = smem + BUF;
+  SK_STAMP(0);
+  // norm hand-over: ALL the producer's partial sums in one round trip (512 threads, <= 2 loads each), issued FIRST so that
+  // waiting for them leaves the activation and weight loads in flight.  (The former 16-thread loop paid one L2 / memory
+  // round trip per 8 parts behind the weight loads, which made the hand-over a wash.)  Straight-line: no load under a branch.
+  constexpr int SQ_LD = MT == 1 ? SQ_PARTS_MAX * 16 / (SK_NW * 64) : 1;
+  float pv[SQ_LD];
+  if constexpr (MT == 1) {
+    const float* sqsrc = norm ? p.sq_in : (const float*)p.x;
+    const int nsq = norm ? p.sq_parts * 16 : 1;     // host: sq_parts <= SQ_PARTS_MAX
+#pragma unroll
+    for (int u = 0; u < SQ_LD; ++u) pv[u] = sqsrc[min(tid + u * (SK_NW * 64), nsq - 1)];
+  }
   load_x(c0);
 #pragma unroll
   for (int u = 0; u < UK; ++u) issue(u, u_begin + u);
+  // residual epilogue (<= 16 rows): h is fetched now -- no other workgroup of this launch writes these columns -- instead of
+  // as one more dependent round trip at the very end of the last arriver's chain.  Straight-line (pointer select).
+  constexpr bool HPRE = !SWIGLU && MT == 1;
+  float hpre[HPRE ? MT * 4 : 1];
+  if constexpr (HPRE) {
+    const bool res = p.epi == EPI_RESID;
+    const XT* hp = res ? (const XT*)p.resid : (const XT*)p.out;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        hpre[mt * 4 + r] = (float)hp[(size_t)min(mt * 16 + g * 4 + r, p.M - 1) * p.ldo + tile * 16 + c16];
+  }
   if constexpr (MT == 1) {
-    if (norm) {                                   // 16 threads: row statistics from the producer's partial sums
+    if (norm) {
+      // thread t holds parts (t >> 4) + 32 u of row t & 15: a fixed tree -- the two registers, lanes +16 / +32 of the wave
+      // (4 parts), then the 8 waves through LDS
+      float v = 0.f;
+#pragma unroll
+      for (int u = 0; u < SQ_LD; ++u) v += (tid + u * (SK_NW * 64) < p.sq_parts * 16) ? pv[u] : 0.f;
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16) sqp_sh[wave * 16 + lane] = v;
+      __syncthreads();
       if (tid < 16) {
-        float v = 0.f;
-        for (int j = 0; j < p.sq_parts; j += 8) {
-          float pv[8];
+        float t = 0.f;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) pv[u] = p.sq_in[(size_t)min(j + u, p.sq_parts - 1) * 16 + tid];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (j + u < p.sq_parts) v += pv[u];
-        }
-        rs_sh[tid] = 1.0f / sqrtf(v / (float)p.K + p.eps);
+        for (int w = 0; w < SK_NW; ++w) t += sqp_sh[w * 16 + tid];
+        rs_sh[tid] = 1.0f / sqrtf(t / (float)p.K + p.eps);
       }
       __syncthreads();
     }
   }
+  SK_STAMP(1);
   store_x(c0, cur);
   __syncthreads();
+  SK_STAMP(2);
 
   // ================= the slice
   for (int c = c0; c < c1; c += CPI) {
@@ -436,6 +476,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
     }
   }
 
+  SK_STAMP(3);
   // ================= deferred RMSNorm: this slice's sum of x^2 per row, in a fixed order (8 lanes of a piece by DPP,
   // then the 4 k-groups of the chunk through LDS)
   __shared__ float rs_row[32];
@@ -481,6 +522,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have left
     __syncthreads();
+    SK_STAMP(4);
     if (tid == 0) {
       const unsigned old = __hip_atomic_fetch_add(&p.ctr[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = old == (unsigned)(p.ksplit - 1);
@@ -488,13 +530,17 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       last_sh = last;
     }
     __syncthreads();
+    SK_STAMP(5);
     if (!last_sh) return;
     if constexpr (X32) {
       if (dn) {                                  // the slices' sums of squares, in slice order
+        float* sqs = (float*)smem;               // [ksplit][MB] (ksplit <= 16, MB <= 32: one load per thread, one round trip)
+        if (tid < p.ksplit * MB)
+          sqs[tid] = __hip_atomic_load(&p.sqws[(size_t)grp * p.ksplit * MB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
         if (tid < MB) {
           float tot = 0.f;
-          for (int s2 = 0; s2 < p.ksplit; ++s2)
-            tot += __hip_atomic_load(&p.sqws[((size_t)grp * p.ksplit + s2) * MB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int s2 = 0; s2 < p.ksplit; ++s2) tot += sqs[s2 * MB + tid];
           rs_row[tid] = 1.0f / sqrtf(tot / (float)p.K + p.eps);
         }
         __syncthreads();
@@ -505,20 +551,53 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-      for (int s2 = 0; s2 < p.ksplit; ++s2) {     // slice order, whoever arrived last
-        const float* rp = p.ws + (((size_t)(s2 * p.ntiles + tile) * (NA * MT)) * 64 + lane) * 4;
+      // slice order, whoever arrived last; CB slices' partials are fetched per round trip (they come from other XCDs,
+      // i.e. from memory: with one slice per trip the o_proj / down_proj combines spent 3-4 trips here) at <= 32 rows
+      if constexpr (NA * MT <= 2) {
+        constexpr int CB = 8;
+        for (int sb = 0; sb < p.ksplit; sb += CB) {
+          u32x4 pvv[CB][NA][MT];
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+          for (int j = 0; j < CB; ++j) {
+            if (sb + j < p.ksplit) {            // (uniform; nothing else is in flight here)
+              const float* rp = p.ws + (((size_t)((sb + j) * p.ntiles + tile) * (NA * MT)) * 64 + lane) * 4;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const u32x4 v = load16_agent(rp + (size_t)(a * MT + mt) * 256);
-            acc[a][mt].x += __uint_as_float(v.x); acc[a][mt].y += __uint_as_float(v.y);
-            acc[a][mt].z += __uint_as_float(v.z); acc[a][mt].w += __uint_as_float(v.w);
+              for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) pvv[j][a][mt] = load16_agent(rp + (size_t)(a * MT + mt) * 256);
+            }
           }
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            if (sb + j < p.ksplit) {
+#pragma unroll
+              for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                  const u32x4 v = pvv[j][a][mt];
+                  acc[a][mt].x += __uint_as_float(v.x); acc[a][mt].y += __uint_as_float(v.y);
+                  acc[a][mt].z += __uint_as_float(v.z); acc[a][mt].w += __uint_as_float(v.w);
+                }
+            }
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int s2 = 0; s2 < p.ksplit; ++s2) {
+          const float* rp = p.ws + (((size_t)(s2 * p.ntiles + tile) * (NA * MT)) * 64 + lane) * 4;
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const u32x4 v = load16_agent(rp + (size_t)(a * MT + mt) * 256);
+              acc[a][mt].x += __uint_as_float(v.x); acc[a][mt].y += __uint_as_float(v.y);
+              acc[a][mt].z += __uint_as_float(v.z); acc[a][mt].w += __uint_as_float(v.w);
+            }
+        }
       }
     }
   }
+  SK_STAMP(6);
   const bool want_sq = (MT == 1) && p.sq_out != nullptr;      // (uniform; then spare waves stay for the barriers below)
   if (!valid && !want_sq) return;
 
@@ -546,7 +625,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           const float y = round_rt(y0, p.rnd);
           if (p.epi == EPI_RESID) {
             float* h = (float*)p.resid;
-            h[(size_t)m * p.ldo + n] = round_rt(h[(size_t)m * p.ldo + n] + y, p.rnd);
+            float hv;
+            if constexpr (HPRE) hv = hpre[mt * 4 + r]; else hv = h[(size_t)m * p.ldo + n];
+            h[(size_t)m * p.ldo + n] = round_rt(hv + y, p.rnd);
           } else {
             o32[(size_t)m * p.ldo + n] = y;     // EPI_STORE and EPI_STORE_F32 coincide
           }
@@ -579,7 +660,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         else if (p.epi == EPI_STORE_F32) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
         else {
           AT* h = (AT*)p.resid;
-          const AT hv = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+          float h0;
+          if constexpr (HPRE) h0 = hpre[mt * 4 + r]; else h0 = (float)h[(size_t)m * p.ldo + n];
+          const AT hv = (AT)(h0 + y);
           h[(size_t)m * p.ldo + n] = hv;
           if constexpr (MT == 1) hsq[r] = (float)hv * (float)hv;
         }
@@ -602,6 +685,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       }
     }
   }
+  SK_STAMP(7);
 }
 
 // 16-row tiles of activations per workgroup: 1, 2, 3, 4, 6 or 8 (65..96 rows -> 6, 97..128 -> 8)
@@ -622,17 +706,35 @@ SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
   pl.ntiles = (c.epi == EPI_SWIGLU ? c.pair_offset : W.N) / 16;
   pl.ngroups = (pl.ntiles + SK_NW - 1) / SK_NW;
   pl.nchunks = (W.K + SK_KC - 1) / SK_KC;
-  const double cus = gemv_cu_count(), bw = 6.3e12, r_max = 40e9;
-  const double bpe = (W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16) ? 1.0625 : wk_is_quant(W.wk) ? 0.5625 : 2.0;
+  const bool quant = wk_is_quant(W.wk), q8 = W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16;
+  const double cus = gemv_cu_count(), bw = 6.3e12;
+  const double bpe = q8 ? 1.0625 : quant ? 0.5625 : 2.0;
   const double unit_p = 2.0 * SK_NW * 16 * pl.na * pl.mt * 16 * 4;          // written + read
+  // what ONE CU moves: r1 with one workgroup on it, r2 with two or more (quantised weights at <= 32 rows keep two
+  // resident: <= 128 VGPRs, 17 KiB LDS).  int4: the loop is bound by the dequantisation -- measured 28 GB/s alone (Qwen3-14B
+  // gate|up at ksplit 1: 136 workgroups streamed at 3.85 TB/s) and ~35 GB/s for a pair; that shape now splits 3 ways
+  // (408 workgroups, 1880 -> 2117 tok/s).  Everything else keeps the rates the model was fitted with.
+  const bool q4_small = quant && !q8 && pl.mt <= 2 && c.act != MI_F32;
+  const double r1 = q4_small ? 28e9 : 40e9, r2 = q4_small ? 35.5e9 : 40e9;
   double best = 0.0;
   pl.ksplit = 1;
   for (int s = 1; s <= std::min(16, pl.nchunks); ++s) {
     const double units = (double)pl.ngroups * s;
-    const double unit_w = (double)SK_NW * 16 * pl.na * bpe * SK_KC * ((pl.nchunks + s - 1) / s);
-    const double rate = std::min(r_max, bw / std::min(units, cus));
-    const double t = std::ceil(units / cus) * (unit_w + (s > 1 ? unit_p : 0.0)) / rate;
+    const double unit = (double)SK_NW * 16 * pl.na * bpe * SK_KC * ((pl.nchunks + s - 1) / s) + (s > 1 ? unit_p : 0.0);
+    const double k = std::ceil(units / cus);                               // workgroups on the busiest CU
+    const double t = q4_small ? std::max(units * unit / bw, k * unit / (k == 1.0 ? r1 : r2)) + 0.2e-6 * s   // (+ the last arriver's read per slice)
+                              : k * std::max(std::min(units, cus) * unit / bw, unit / r1);
     if (s == 1 || t < best * 0.97) { best = t; pl.ksplit = s; }            // a larger split has to earn its partials
+  }
+  // A/B: MI_SKINNY_FORCE="N:K:ksplit,..." overrides the model for the linears named
+  static const char* force = getenv("MI_SKINNY_FORCE");
+  if (force != nullptr) {
+    for (const char* q = force; *q;) {
+      int fn = 0, fk = 0, fs = 0;
+      if (sscanf(q, "%d:%d:%d", &fn, &fk, &fs) == 3 && fn == W.N && fk == W.K && fs >= 1) pl.ksplit = std::min(fs, std::min(16, pl.nchunks));
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
   }
   pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024 : 0;
   if (pl.ksplit > 1 && c.act == MI_F32 && c.pro == PRO_NORM)       // deferred RMSNorm: the K slices' row sums of squares
@@ -729,13 +831,42 @@ size_t gemm_skinny_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows) { 
 int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ngroups; }
 
 // c.pro must be PRO_NONE (normalise first); `ws` holds gemm_skinny_ws_bytes(), `ctr` gemm_skinny_groups() zeroed words
+#ifdef MI_SK_TRACE
+namespace {
+struct SkTraceRec { int launch, N, K, ksplit, grid, epi, M, qb, pro, act, mt, pad; };
+constexpr int TR_LAUNCHES = 4096, TR_WG = 1024;
+unsigned long long* tr_buf = nullptr;
+SkTraceRec tr_rec[TR_LAUNCHES];
+long tr_count = 0;
+}
+extern "C" int mi_debug_sk_trace_dump(const char* path) {
+  if (!tr_buf) return 1;
+  hipDeviceSynchronize();
+  const long n = std::min<long>(tr_count, TR_LAUNCHES);
+  FILE* f = fopen(path, "wb");
+  if (!f) return 2;
+  std::vector<unsigned long long> h((size_t)TR_WG * 8);
+  fwrite(&n, sizeof(long), 1, f);
+  for (long i = tr_count - n; i < tr_count; ++i) {
+    const SkTraceRec& r = tr_rec[i % TR_LAUNCHES];
+    hipMemcpy(h.data(), tr_buf + (size_t)(i % TR_LAUNCHES) * TR_WG * 8, (size_t)r.grid * 64, hipMemcpyDeviceToHost);
+    fwrite(&r, sizeof(r), 1, f);
+    fwrite(h.data(), 8, (size_t)r.grid * 8, f);
+  }
+  fclose(f);
+  return 0;
+}
+#endif
+
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr, int ksplit) {
   const bool defer_norm = c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && c.norm_w != nullptr;
   if (c.pro != PRO_NONE && !defer_norm && !(rows <= 16 && c.sq_in != nullptr && c.sq_parts > 0))
     return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first (or hand over the row sums of squares)");
+  if (c.sq_in != nullptr && c.sq_parts > SQ_PARTS_MAX) return fail(MI_ERR_INVALID, "gemm_skinny: norm hand-over from more than 64 tile groups");
   SkinnyPlan pl = skinny_plan(W, c, rows);
   if (ksplit > 0) {
     pl.ksplit = std::min(ksplit, pl.nchunks);
+    if (defer_norm) pl.ksplit = std::min(pl.ksplit, 16);
     pl.ws_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * pl.ntiles * pl.na * pl.mt * 1024 : 0;
     if (pl.ksplit > 1 && defer_norm) pl.ws_bytes += (size_t)pl.ngroups * pl.ksplit * 16 * pl.mt * sizeof(float);
   }
@@ -758,6 +889,12 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   const int qb = (W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16) ? 8 : wk_is_quant(W.wk) ? 4 : 0;
   const bool sw = c.epi == EPI_SWIGLU;
   const int grid = pl.ngroups * pl.ksplit;
+#ifdef MI_SK_TRACE
+  if (!tr_buf) { MI_HIP(hipMalloc(&tr_buf, (size_t)TR_LAUNCHES * TR_WG * 64)); MI_HIP(hipMemset(tr_buf, 0, (size_t)TR_LAUNCHES * TR_WG * 64)); }
+  tr_rec[tr_count % TR_LAUNCHES] = SkTraceRec{(int)tr_count, W.N, W.K, pl.ksplit, std::min(grid, TR_WG), c.epi, (int)rows, qb, c.pro, c.act, pl.mt, 0};
+  p.trace = tr_buf + (size_t)(tr_count % TR_LAUNCHES) * TR_WG * 8;
+  ++tr_count;
+#endif
   if (c.act == MI_F32) {
     p.sq_out = nullptr; p.sq_in = nullptr;
     auto launch32 = [&](auto kern) -> int {

@@ -85,7 +85,7 @@ def checkpoints(tmp_path_factory):
 
 
 def test_wide_golden_files_present():
-    assert len(WIDE) >= 12, "run tests/golden/make_golden_wide.py"
+    assert len(WIDE) >= 17, "run tests/golden/make_golden_wide.py"
 
 
 @pytest.mark.parametrize("path", WIDE, ids=[p.stem for p in WIDE])
