@@ -90,7 +90,7 @@ struct SkinnyParams {
 };
 
 #ifdef MI_SK_TRACE
-#define SK_STAMP(i) do { if (tid == 0) p.trace[(size_t)(blockIdx.x & 1023) * 8 + (i)] = wall_clock64(); } while (0)
+#define SK_STAMP(i) do { if (tid == 0) p.trace[(size_t)(blockIdx.x & 1023) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define SK_STAMP(i) do { } while (0)
 #endif
@@ -117,6 +117,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   __shared__ int last_sh;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
+#ifdef MI_SK_TRACE_ENTRY
+  if (lane == 0) p.trace[(size_t)(blockIdx.x & 1023) * 16 + 8 + wave] = wall_clock64();     // every wave: entry
+#endif
   const int grp = blockIdx.x / p.ksplit, s = blockIdx.x - grp * p.ksplit;
   const int tile_raw = grp * SK_NW + wave;
   const bool valid = tile_raw < p.ntiles;
@@ -452,6 +455,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   }
   SK_STAMP(1);
   store_x(c0, cur);
+#if defined(MI_SK_TRACE) && !defined(MI_SK_TRACE_ENTRY)
+  if (lane == 0) p.trace[(size_t)(blockIdx.x & 1023) * 16 + 8 + wave] = wall_clock64();     // every wave: its share of the first chunk is written
+#endif
   __syncthreads();
   SK_STAMP(2);
 
@@ -845,13 +851,13 @@ extern "C" int mi_debug_sk_trace_dump(const char* path) {
   const long n = std::min<long>(tr_count, TR_LAUNCHES);
   FILE* f = fopen(path, "wb");
   if (!f) return 2;
-  std::vector<unsigned long long> h((size_t)TR_WG * 8);
+  std::vector<unsigned long long> h((size_t)TR_WG * 16);
   fwrite(&n, sizeof(long), 1, f);
   for (long i = tr_count - n; i < tr_count; ++i) {
     const SkTraceRec& r = tr_rec[i % TR_LAUNCHES];
-    hipMemcpy(h.data(), tr_buf + (size_t)(i % TR_LAUNCHES) * TR_WG * 8, (size_t)r.grid * 64, hipMemcpyDeviceToHost);
+    hipMemcpy(h.data(), tr_buf + (size_t)(i % TR_LAUNCHES) * TR_WG * 16, (size_t)r.grid * 128, hipMemcpyDeviceToHost);
     fwrite(&r, sizeof(r), 1, f);
-    fwrite(h.data(), 8, (size_t)r.grid * 8, f);
+    fwrite(h.data(), 8, (size_t)r.grid * 16, f);
   }
   fclose(f);
   return 0;
@@ -890,9 +896,9 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   const bool sw = c.epi == EPI_SWIGLU;
   const int grid = pl.ngroups * pl.ksplit;
 #ifdef MI_SK_TRACE
-  if (!tr_buf) { MI_HIP(hipMalloc(&tr_buf, (size_t)TR_LAUNCHES * TR_WG * 64)); MI_HIP(hipMemset(tr_buf, 0, (size_t)TR_LAUNCHES * TR_WG * 64)); }
+  if (!tr_buf) { MI_HIP(hipMalloc(&tr_buf, (size_t)TR_LAUNCHES * TR_WG * 128)); MI_HIP(hipMemset(tr_buf, 0, (size_t)TR_LAUNCHES * TR_WG * 128)); }
   tr_rec[tr_count % TR_LAUNCHES] = SkTraceRec{(int)tr_count, W.N, W.K, pl.ksplit, std::min(grid, TR_WG), c.epi, (int)rows, qb, c.pro, c.act, pl.mt, 0};
-  p.trace = tr_buf + (size_t)(tr_count % TR_LAUNCHES) * TR_WG * 8;
+  p.trace = tr_buf + (size_t)(tr_count % TR_LAUNCHES) * TR_WG * 16;
   ++tr_count;
 #endif
   if (c.act == MI_F32) {

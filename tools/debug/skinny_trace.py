@@ -9,7 +9,8 @@ Build the library with -DMI_SK_TRACE (tools/debug/build_trace_lib.sh), then on a
 Runs bench.py's decode leg (4 timed steps), dumps the per-workgroup wall-clock stamps (100 MHz s_memrealtime) of the
 last launches and prints, per linear of the decode step, the average of:
   ramp    first workgroup's entry -> last workgroup's entry
-  stage   entry -> first activation chunk staged (x load, norm hand-over, LDS store, barrier)
+  stage_norm / w0..w7 / stage   entry -> row statistics known / wave w has written its share of the first activation
+          chunk / the chunk is complete (barrier)
   stream  the K slice (weights streamed, MFMA)
   publish partial tile stored write-through + drained
   count   arrival counter
@@ -39,7 +40,7 @@ def read_dump(path):
             grid = hdr[4]
             import numpy as np
 
-            st = np.frombuffer(f.read(grid * 64), dtype=np.uint64).reshape(grid, 8).astype(np.int64)
+            st = np.frombuffer(f.read(grid * 128), dtype=np.uint64).reshape(grid, 16).astype(np.int64)
             recs.append((hdr, st))
     return recs
 
@@ -103,6 +104,8 @@ def report(path, steps):
         a["ramp"].append((st[:, 0].max() - s0) * TICK_US)
         a["stage"].append(np.mean(st[:, 2] - st[:, 0]) * TICK_US)
         a["stage_norm"].append(np.mean(st[:, 1] - st[:, 0]) * TICK_US)
+        for w in range(8):
+            a[f"w{w}"].append(np.mean(st[:, 8 + w] - st[:, 0]) * TICK_US)
         a["stream"].append(np.mean(st[:, 3] - st[:, 2]) * TICK_US)
         if h[3] > 1:
             a["publish"].append(np.mean(st[:, 4] - st[:, 3]) * TICK_US)
@@ -120,11 +123,11 @@ def report(path, steps):
         a["last_stream_end"].append((st[:, 3].max() - s0) * TICK_US)
         if j + 1 < len(sel):
             a["to_next"].append((sel[j + 1][1][:, 0].min() - end) * TICK_US)
-    cols = ["ramp", "stage_norm", "stage", "stream", "last_stream_end", "publish", "count", "combine", "epi", "total", "to_next"]
-    print(f"{'linear':<10}{'N':>7}{'K':>7}{'ksplit':>7}{'grid':>6}{'mt':>3} " + " ".join(f"{c:>10}" for c in cols))
+    cols = ["ramp", "stage_norm", "w0", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "stage", "stream", "last_stream_end", "publish", "count", "combine", "epi", "total", "to_next"]
+    print(f"{'linear':<10}{'N':>7}{'K':>7}{'ksplit':>7}{'grid':>6}{'mt':>3} " + " ".join(f"{c:>7}" for c in cols))
     for key in rows:
         a = acc[key]
-        print(f"{key[0]:<10}{key[1]:>7}{key[2]:>7}{key[3]:>7}{key[4]:>6}{key[5]:>3} " + " ".join(f"{np.mean(a[c]):>10.2f}" for c in cols))
+        print(f"{key[0]:<10}{key[1]:>7}{key[2]:>7}{key[3]:>7}{key[4]:>6}{key[5]:>3} " + " ".join(f"{np.mean(a[c]):>7.2f}" for c in cols))
 
 
 if __name__ == "__main__":
