@@ -164,6 +164,7 @@ struct Phase {
   uint32_t sr[NA][TB][UK], br[NA][TB][UK];
   u32x4 xv[MB][J];
   f32x4 acc[NA][TB];
+  float hpre = 0.f; bool hpre_ok = false;   // residual epilogue: h of this workgroup's FIRST tile, fetched at the head of the phase
 
   __device__ __forceinline__ Phase(const MfmaParams& pp, unsigned char* smem) : p(pp) {
     nbuf = DB ? 2 : 1;
@@ -396,7 +397,8 @@ struct Phase {
             else if (p.epi == EPI_STORE_F32) ((float*)p.out)[(size_t)m * p.ldo + n] = y;
             else {
               AT* h = (AT*)p.resid;
-              store_elem<AT>(&h[(size_t)m * p.ldo + n], (AT)((float)h[(size_t)m * p.ldo + n] + y), WT);
+              const float h0 = (hpre_ok && tile == 0) ? hpre : (float)h[(size_t)m * p.ldo + n];
+              store_elem<AT>(&h[(size_t)m * p.ldo + n], (AT)(h0 + y), WT);
             }
           }
         }
@@ -422,6 +424,18 @@ struct Phase {
     // ================= prologue: activations first (older in the vmcnt queue), then weights
     if (ntiles > 0) load_x<COH>(0, klen0);
     if constexpr (!PREFETCHED) prefetch_weights();
+    if constexpr (!COH && !SWIGLU) {
+      // residual epilogue: the h values of the first tile now -- only this workgroup writes them in this launch -- instead of
+      // as a dependent load after the cross-wave reduction, at the very end of the chain (o_proj / down_proj: one tile per
+      // workgroup).  Straight-line: the pointer is selected, the load is not under a branch.
+      const bool res = p.epi == EPI_RESID && ntiles > 0;
+      const AT* hp = res ? (const AT*)p.resid : (const AT*)p.x;
+      const int el = tid & 63, r = (tid >> 6) & 3;
+      const int mm = min(4 * (el >> 4) + r, p.M - 1);
+      const size_t off = res ? (size_t)mm * p.ldo + item_row0(0) + (el & 15) : 0;
+      hpre = (float)hp[off];
+      hpre_ok = res;
+    }
     if (p.pro == PRO_NORM) {
       float ss[MB];
 #pragma unroll
