@@ -845,6 +845,17 @@ unsigned long long* tr_buf = nullptr;
 SkTraceRec tr_rec[TR_LAUNCHES];
 long tr_count = 0;
 }
+// the stamp slab of one launch of ANOTHER kernel family (gemv_mfma.hip); `kind` goes to the record's qb field (-1 = gemv_mfma)
+unsigned long long* dbg_trace_slot(int N, int K, int grid, int epi, int M, int kind, int pro, int act) {
+  if (!tr_buf) {
+    if (hipMalloc(&tr_buf, (size_t)TR_LAUNCHES * TR_WG * 128) != hipSuccess) return nullptr;
+    hipMemset(tr_buf, 0, (size_t)TR_LAUNCHES * TR_WG * 128);
+  }
+  tr_rec[tr_count % TR_LAUNCHES] = SkTraceRec{(int)tr_count, N, K, 1, std::min(grid, TR_WG), epi, M, kind, pro, act, 1, 0};
+  unsigned long long* p = tr_buf + (size_t)(tr_count % TR_LAUNCHES) * TR_WG * 16;
+  ++tr_count;
+  return p;
+}
 extern "C" int mi_debug_sk_trace_dump(const char* path) {
   if (!tr_buf) return 1;
   hipDeviceSynchronize();

@@ -35,6 +35,10 @@
 
 namespace mi {
 
+#ifdef MI_SK_TRACE
+unsigned long long* dbg_trace_slot(int N, int K, int grid, int epi, int M, int kind, int pro, int act);   // gemm_skinny.hip
+#endif
+
 namespace {
 
 using namespace gemv;
@@ -83,6 +87,14 @@ int launch_j(const MfmaParams& p, hipStream_t st) {
   const size_t lds = phase_lds_bytes<NW, NA, Q4>(p.kc, MB, DB ? 2 : 1);
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = std::min(p.N / 16, cu_count());        // one workgroup per CU; items are dealt in-kernel
+#ifdef MI_SK_TRACE
+  MfmaParams pt = p;
+  pt.trace = dbg_trace_slot(p.N, p.K, nwg, p.epi, p.M, Q4 ? -4 : -1, p.pro, MI_BF16);
+  if (g_ev_start != nullptr) hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, g_ev_start, g_ev_stop, 0, pt);
+  else hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, pt);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+#endif
   if (g_ev_start != nullptr)   // measurement: dispatch-level begin/end timestamps of THIS kernel
     hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds, st, g_ev_start, g_ev_stop, 0, p);
   else

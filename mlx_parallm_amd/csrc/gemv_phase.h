@@ -26,7 +26,18 @@ struct MfmaParams {
   const float* lora_b0; const float* lora_b1;
   int lora_row0_0, lora_n_0, lora_rank_0; float lora_scale_0;
   int lora_row0_1, lora_n_1, lora_rank_1; float lora_scale_1;
+#ifdef MI_SK_TRACE
+  unsigned long long* trace;       // debug build (tools/debug/build_trace_lib.sh): [workgroup][16] wall-clock stamps
+#endif
 };
+
+#ifdef MI_SK_TRACE
+#define PH_STAMP(i) do { if (p.trace != nullptr && tid == 0) p.trace[(size_t)(w & 1023) * 16 + (i)] = wall_clock64(); } while (0)
+#define PH_STAMP_WAVE(i) do { if (p.trace != nullptr && lane == 0) p.trace[(size_t)(w & 1023) * 16 + (i) + wave] = wall_clock64(); } while (0)
+#else
+#define PH_STAMP(i) do { } while (0)
+#define PH_STAMP_WAVE(i) do { } while (0)
+#endif
 
 // in-launch seam of gemv_pair_kernel: every workgroup adds 1 to *counter after phase A; phase B starts
 // when the counter has reached `target`.  A workgroup that polls `spin_limit` times without seeing it
@@ -422,6 +433,7 @@ struct Phase {
   template <bool PREFETCHED, bool COH, bool WT>
   __device__ __forceinline__ void run() {
     // ================= prologue: activations first (older in the vmcnt queue), then weights
+    PH_STAMP(0);
     if (ntiles > 0) load_x<COH>(0, klen0);
     if constexpr (!PREFETCHED) prefetch_weights();
     if constexpr (!COH && !SWIGLU) {
@@ -479,8 +491,10 @@ struct Phase {
       }
       __syncthreads();
     }
+    PH_STAMP(1);
     if (ntiles > 0) stage_x(0, klen0);
     __syncthreads();
+    PH_STAMP(2);
     if (ntiles <= 0) return;
     int staged = 0;
     prefetch_next_x<COH>(0, 0);
@@ -535,9 +549,11 @@ struct Phase {
           prefetch_next_x<COH>(nc, nc == 0 ? tb + 1 : tb);
         }
       }
+      if (tb == nbatch - 1) { PH_STAMP(3); PH_STAMP_WAVE(8); }
       finish<WT>(tb);
       __syncthreads();                          // `red` / fragments are reused
     }
+    PH_STAMP(7);
   }
 };
 

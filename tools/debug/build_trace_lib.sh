@@ -4,6 +4,9 @@ set -e
 cd "$(dirname "$0")/../../mlx_parallm_amd/csrc"
 make -s
 mkdir -p alt
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMI_SK_TRACE -c gemm_skinny.hip -o alt/gemm_skinny_trace.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 engine.o gemv_v1.o gemv_mfma.o gemm_prefill.o alt/gemm_skinny_trace.o attn.o attn_decode.o attn_prefill.o misc.o repack.o ops_api.o -o alt/libmi355_trace.so
+# (MfmaParams / SkinnyParams grow a trace pointer: every unit that sees them is rebuilt with the macro)
+for f in gemm_skinny gemv_mfma attn_decode; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMI_SK_TRACE $TRACE_FLAGS -c $f.hip -o alt/${f}_trace.o
+done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 engine.o gemv_v1.o alt/gemv_mfma_trace.o gemm_prefill.o alt/gemm_skinny_trace.o attn.o alt/attn_decode_trace.o attn_prefill.o misc.o repack.o ops_api.o -o alt/libmi355_trace.so
 echo built alt/libmi355_trace.so
