@@ -236,6 +236,7 @@ struct Phase {
   // the first batch's weights: independent of any activation, so a caller may issue them early
   __device__ __forceinline__ void prefetch_weights() { issue_w(0, 0, ntiles > 0 ? klen0 : 0); }
 
+
   template <bool COH>
   __device__ __forceinline__ void load_x(int kbase, int klen) {
     const int n8 = klen / 8;
