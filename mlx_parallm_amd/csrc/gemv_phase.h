@@ -122,6 +122,29 @@ __device__ __forceinline__ u32x4 load16_agent(const void* p) {
   return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
 }
 
+// a dword of two 16-bit floats <-> two floats (element 0 in the low half)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename AT>
+__device__ __forceinline__ f32x2 unpack2(uint32_t v) {
+  if constexpr (std::is_same<AT, bf16>::value) {
+    return f32x2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+  } else {
+    const f16x2 h = __builtin_bit_cast(f16x2, v);
+    return f32x2{(float)h.x, (float)h.y};
+  }
+}
+template <typename AT>
+__device__ __forceinline__ uint32_t pack2(f32x2 f) {
+  // round to nearest even, both halves in ONE v_cvt_pk_{bf16,f16}_f32 (written element by element hipcc converts each
+  // half on its own and merges them with shifts)
+  if constexpr (std::is_same<AT, bf16>::value) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+  } else {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
+  }
+}
+
 template <typename AT>
 __device__ __forceinline__ void store_elem(AT* p, AT v, bool write_through) {
   if (write_through) {
@@ -254,30 +277,37 @@ struct Phase {
       }
   }
 
-  // xv -> (RMSNorm) -> MFMA A-fragments in LDS
+  // xv -> (RMSNorm) -> MFMA A-fragments in LDS.  The normalisation is written on dword pairs (two floats per v_pk_mul_f32,
+  // one v_cvt_pk per rounding) and the norm weights are unpacked once for the MB rows: this pass is ~450 VALU instructions
+  // per thread in front of the first MFMA of every normalised linear, on every workgroup.
   __device__ __forceinline__ void stage_x(int kbase, int klen) {
     const int n8 = klen / 8;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int j = 0; j < J; ++j) {
+      const int k8 = tid + j * NT;
+      if (k8 < n8) {
+        f32x2 wf[4];
+        if (p.pro == PRO_NORM) {
+          const u32x4 wv = *(const u32x4*)((const AT*)p.norm_w + kbase + k8 * 8);
+          wf[0] = unpack2<AT>(wv.x); wf[1] = unpack2<AT>(wv.y); wf[2] = unpack2<AT>(wv.z); wf[3] = unpack2<AT>(wv.w);
+        }
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int k8 = tid + j * NT;
-        if (k8 < n8) {
+        for (int m = 0; m < MB; ++m) {
           u32x4 v = xv[m][j];
-          AT* e = (AT*)&v;
           float sum = 0.f;
           if (m < p.M) {
             if (p.pro == PRO_NORM) {
-              const u32x4 wv = *(const u32x4*)((const AT*)p.norm_w + kbase + k8 * 8);
-              const AT* we = (const AT*)&wv;
               const float rs = rs_sh[m];
+              const f32x2 rs2 = {rs, rs};
+              uint32_t* d = (uint32_t*)&v;
 #pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const AT xn = (AT)((float)e[i] * rs);              // cast_T(x32 * rsqrt(..))
-                e[i] = (AT)((float)xn * (float)we[i]);            // w * (.)  in T
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t xn = pack2<AT>(unpack2<AT>(d[i]) * rs2);      // cast_T(x32 * rsqrt(..))
+                d[i] = pack2<AT>(unpack2<AT>(xn) * wf[i]);                  // w * (.)  in T
               }
             }
             if constexpr (Q4) {
+              AT* e = (AT*)&v;
 #pragma unroll
               for (int i = 0; i < 8; ++i) sum += (float)e[i];
               AT t2[8];                                            // nibble order: 2q <- k+q, 2q+1 <- k+q+4
@@ -295,6 +325,7 @@ struct Phase {
           }
         }
       }
+    }
   }
 
   __device__ __forceinline__ void zero_acc() {
@@ -456,13 +487,16 @@ struct Phase {
       if (ntiles > 0) {
         if (nchunks == 1) {
 #pragma unroll
-          for (int m = 0; m < MB; ++m)
+          for (int m = 0; m < MB; ++m) {
+            f32x2 s2 = {0.f, 0.f};                     // dword pairs: two unpacks + one v_pk_fma_f32 per two elements
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-              const AT* e = (const AT*)&xv[m][j];
+              const uint32_t* d = (const uint32_t*)&xv[m][j];
 #pragma unroll
-              for (int i = 0; i < 8; ++i) { const float f = (float)e[i]; ss[m] = fmaf(f, f, ss[m]); }
+              for (int i = 0; i < 4; ++i) { const f32x2 f = unpack2<AT>(d[i]); s2 = f * f + s2; }
             }
+            ss[m] = s2.x + s2.y;
+          }
         } else {
           for (int k = tid * 8; k < p.K; k += NT * 8) {
 #pragma unroll
