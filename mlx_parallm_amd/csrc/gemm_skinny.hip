@@ -611,6 +611,21 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   const int n = tile * 16 + c16;
   AT* out = (AT*)p.out;
   float hsq[4] = {0.f, 0.f, 0.f, 0.f};
+  // residual epilogue above 16 rows: ALL of the lane's h values in one round trip.  Left to the loop below, every h load sat
+  // behind the previous h store (same array: the compiler keeps the order) -- 16 dependent round trips at 64 rows, 6.5 us of
+  // o_proj's 24.6 (stamps, Qwen3-14B int4, B = 64).
+  constexpr bool HLATE = !SWIGLU && MT > 1;
+  float hlate[HLATE ? MT * 4 : 1];
+  if constexpr (HLATE) {
+    if (p.epi == EPI_RESID) {                    // (uniform; nothing else is in flight here)
+      const XT* hp = (const XT*)p.resid;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          hlate[mt * 4 + r] = (float)hp[(size_t)min(mt * 16 + g * 4 + r, p.M - 1) * p.ldo + n];
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -632,7 +647,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           if (p.epi == EPI_RESID) {
             float* h = (float*)p.resid;
             float hv;
-            if constexpr (HPRE) hv = hpre[mt * 4 + r]; else hv = h[(size_t)m * p.ldo + n];
+            if constexpr (HPRE) hv = hpre[mt * 4 + r];
+            else if constexpr (HLATE) hv = hlate[mt * 4 + r];
+            else hv = h[(size_t)m * p.ldo + n];
             h[(size_t)m * p.ldo + n] = round_rt(hv + y, p.rnd);
           } else {
             o32[(size_t)m * p.ldo + n] = y;     // EPI_STORE and EPI_STORE_F32 coincide
@@ -667,7 +684,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         else {
           AT* h = (AT*)p.resid;
           float h0;
-          if constexpr (HPRE) h0 = hpre[mt * 4 + r]; else h0 = (float)h[(size_t)m * p.ldo + n];
+          if constexpr (HPRE) h0 = hpre[mt * 4 + r];
+          else if constexpr (HLATE) h0 = hlate[mt * 4 + r];
+          else h0 = (float)h[(size_t)m * p.ldo + n];
           const AT hv = (AT)(h0 + y);
           h[(size_t)m * p.ldo + n] = hv;
           if constexpr (MT == 1) hsq[r] = (float)hv * (float)hv;
@@ -721,15 +740,24 @@ SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
   // gate|up at ksplit 1: 136 workgroups streamed at 3.85 TB/s) and ~35 GB/s for a pair; that shape now splits 3 ways
   // (408 workgroups, 1880 -> 2117 tok/s).  Everything else keeps the rates the model was fitted with.
   const bool q4_small = quant && !q8 && pl.mt <= 2 && c.act != MI_F32;
-  const double r1 = q4_small ? 28e9 : 40e9, r2 = q4_small ? 35.5e9 : 40e9;
+  // int4 above 32 rows: ONE workgroup per CU (150-200 VGPRs) and its loop is bound by the work per weight block, which grows
+  // with the row tiles (stamps, Qwen3-14B int4 at 64 rows: 9-13 GB/s per workgroup; gate|up ran unsplit on 136 CUs at
+  // 1.7 TB/s).  With the rate the model was fitted with (40 GB/s) it priced a second round above the idle CUs.
+  const bool q4_big = quant && !q8 && pl.mt > 2 && c.act != MI_F32;
+  const double r_big = 28e9 / (1.0 + 0.45 * (pl.mt - 1));
+  const double r1 = q4_small ? 28e9 : q4_big ? r_big : 40e9, r2 = q4_small ? 35.5e9 : r1;
   double best = 0.0;
   pl.ksplit = 1;
   for (int s = 1; s <= std::min(16, pl.nchunks); ++s) {
     const double units = (double)pl.ngroups * s;
-    const double unit = (double)SK_NW * 16 * pl.na * bpe * SK_KC * ((pl.nchunks + s - 1) / s) + (s > 1 ? unit_p : 0.0);
+    const double unit_w = (double)SK_NW * 16 * pl.na * bpe * SK_KC * ((pl.nchunks + s - 1) / s), unit_pp = s > 1 ? unit_p : 0.0;
+    const double unit = unit_w + unit_pp;
     const double k = std::ceil(units / cus);                               // workgroups on the busiest CU
-    const double t = q4_small ? std::max(units * unit / bw, k * unit / (k == 1.0 ? r1 : r2)) + 0.2e-6 * s   // (+ the last arriver's read per slice)
-                              : k * std::max(std::min(units, cus) * unit / bw, unit / r1);
+    const double share = bw / std::min(units, cus);
+    double t;
+    if (q4_small) t = std::max(units * unit / bw, k * unit / (k == 1.0 ? r1 : r2)) + 0.2e-6 * s;   // (+ the last arriver's read per slice)
+    else if (q4_big) t = k * (unit_w / std::min(r1, share) + unit_pp / std::min(40e9, share));     // partial tiles move at the memory rate
+    else t = k * std::max(std::min(units, cus) * unit / bw, unit / r1);
     if (s == 1 || t < best * 0.97) { best = t; pl.ksplit = s; }            // a larger split has to earn its partials
   }
   // A/B: MI_SKINNY_FORCE="N:K:ksplit,..." overrides the model for the linears named
