@@ -10,10 +10,10 @@ while read -r line; do
 done <<'CASES'
 --workload qwen3-14b-int4 --lora 8 --batch 64
 --workload qwen3-14b-int4 --batch 32
+--workload mistral-7b-int4 --batch 8
+--workload mistral-7b-int4 --batch 16
 --workload mistral-7b-int4 --batch 32
 --workload mistral-7b-int4 --batch 64
 --workload mistral-7b-int4 --batch 96
---workload mistral-7b-bf16 --batch 32
---workload qwen3-14b-bf16 --batch 32
---workload mistral-7b-int8 --batch 64
+--workload qwen3-14b-int4 --batch 8
 CASES
