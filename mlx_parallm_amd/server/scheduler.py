@@ -353,8 +353,9 @@ class ContinuousScheduler:
 
         while True:
             with self.cv:
+                # (a finished sequence still in its slot is work too: its row gives its KV blocks back below, not at the next arrival)
                 while not self._stop and not self.pending and inflight is None and not any(
-                        s is not None and not s.finished for s in self.slots) and self._waiters == 0:
+                        s is not None for s in self.slots) and self._waiters == 0:
                     self.cv.wait(timeout=0.5)
                 if self._stop:
                     break
@@ -445,6 +446,11 @@ class ContinuousScheduler:
                     if s is not None and not s.finished:
                         s.finished = "error"
                         self._emit(s, f"\n\nError during generation: {e}", "error")
+                    if s is not None and self.paged:
+                        try:
+                            self.kv.reset_row(i)             # the row's blocks go back to the arena
+                        except Exception:
+                            log.exception("could not release the KV row of a failed sequence")
                     self.slots[i] = None
         # shutdown: anything still queued or running is cut
         for s in list(self.pending) + [x for x in self.slots if x is not None]:

@@ -783,3 +783,76 @@ def test_scheduler_waits_for_kv_blocks_instead_of_failing_live_rows(tiny_dirs):
     assert sched.max_rows_seen == 1                          # never both at once: the arena, not the slots, was the limit
     assert sched.prefix_hit_tokens == 16 and stats["evictions"] >= 0
     model.engine.close()
+
+
+def test_scheduler_soak_random_arrivals_prefixes_and_cancels(tiny_dirs):
+    """120 requests against 4 slots and a 40-block arena (16-token blocks): random prompt lengths around a few shared
+    prefixes (prefix-KV reuse), random max_tokens, every seventh request cancelled while it runs, arrivals in bursts while
+    others decode (chunked prefill in mixed steps, admission by free blocks).  Every request must end exactly once with a
+    sane reason; every uncancelled greedy request must equal the oracle's solo run of its prompt; the arena must be whole
+    again at the end (no leaked blocks, nothing left mapped)."""
+    import threading
+    import time
+
+    from mlx_parallm_amd.server.scheduler import ContinuousScheduler
+
+    d, cfg = tiny_dirs["llama_f32"]
+    model, tok = utils.load(d)
+    ref = ref_generate.load(d, max_pos=512)
+    sched = ContinuousScheduler(model, tok, max_slots=4, kv_dtype="model", chunk_tokens=24, block_tokens=16, kv_blocks=41)
+    sched.start()
+    rng = np.random.default_rng(2024)
+    V = cfg["vocab_size"]
+    prefixes = [rng.integers(3, V, size=n).tolist() for n in (16, 33, 48)]
+    N = 120
+    done, lock, ev = {}, threading.Lock(), threading.Event()
+    dup = []
+
+    def sink(i):
+        def f(seq, delta, reason):
+            if reason is not None:
+                with lock:
+                    if i in done:
+                        dup.append(i)
+                    done[i] = (list(seq.generated), reason)
+                    if len(done) == N:
+                        ev.set()
+        return f
+
+    reqs, seqs = [], []
+    for i in range(N):
+        p = list(prefixes[i % 3]) if i % 4 else []
+        p += rng.integers(3, V, size=int(rng.integers(1, 40))).tolist()
+        mt = int(rng.integers(1, 24))
+        reqs.append((p, mt))
+        seqs.append(sched.submit(p, mt, 0.0, 1.0, sink(i)))
+        if i % 7 == 3:
+            time.sleep(0.002)
+            seqs[-1].cancel()
+        if i % 10 == 9:
+            time.sleep(0.01)                      # a burst, then a pause while the others decode
+    assert ev.wait(timeout=300), f"only {len(done)} of {N} requests finished"
+    time.sleep(0.05)
+    stats = sched.kv.stats()
+    sched.stop()
+    assert not dup, f"finished twice: {dup}"
+    eos = tok.eos_token_id
+    checked = 0
+    for i, (p, mt) in enumerate(reqs):
+        got, reason = done[i]
+        assert reason in ("stop", "length", "cancelled"), (i, reason)
+        if reason == "cancelled":
+            assert i % 7 == 3
+            continue
+        want = []
+        for _, (t, _p) in zip(range(mt), ref_generate.generate_step(np.asarray(p)[None], ref, paged=False)):
+            if int(t[0, 0]) == eos:
+                break
+            want.append(int(t[0, 0]))
+        if i % 3 == 0 or len(p) > 48:             # (the oracle's solo runs are the slow part: a third of them + the long ones)
+            assert got == want, (i, len(p), mt, got, want)
+            checked += 1
+    assert checked >= 40
+    # every row released: the only blocks not free are the ones the prefix cache keeps (and those are evictable)
+    assert stats["free_blocks"] + stats["cached_blocks"] == stats["usable_blocks"], stats
+    model.engine.close()
