@@ -8,12 +8,10 @@ while read -r line; do
   MLX_PARALLM_AMD_LIB=$PWD/mlx_parallm_amd/csrc/alt/$ALT python bench.py --no-cpu-baseline --steps 32 --warmup 4 --no-prefill-timing --no-second-leg $line > gpurun_out/abm_alt_$i.json 2>> gpurun_out/abm.err
   echo "$i $line" >> gpurun_out/abm_cases.txt
 done <<'CASES'
+--workload mistral-7b-bf16
+--workload mistral-7b-bf16 --kv-dtype float32
+--workload mistral-7b-int4
+--workload mistral-7b-bf16 --batch 32
 --workload qwen3-14b-int4 --lora 8 --batch 64
---workload qwen3-14b-int4 --batch 32
---workload mistral-7b-int4 --batch 8
---workload mistral-7b-int4 --batch 16
---workload mistral-7b-int4 --batch 32
---workload mistral-7b-int4 --batch 64
---workload mistral-7b-int4 --batch 96
---workload qwen3-14b-int4 --batch 8
+--workload qwen3-14b-bf16
 CASES
