@@ -82,6 +82,7 @@ struct mi_engine {
   void* h = nullptr; void* qkv = nullptr; void* q = nullptr; void* attn = nullptr; void* act = nullptr;
   float* logits = nullptr; float* lora_t = nullptr;
   int32_t* d_tokens = nullptr; size_t d_tokens_cap = 0;
+  const int32_t* tok_src = nullptr;                       // device-fed step: the embedding reads the sampler's output in place
   int32_t* d_forced = nullptr; size_t d_forced_cap = 0;   // mi_score_tokens targets
   int32_t* d_gather = nullptr;                            // token positions whose hidden state feeds the head (mixed steps)
   float* d_rowpar = nullptr; size_t d_rowpar_cap = 0;     // per-row temperature | top_p of the current step
@@ -295,20 +296,21 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
   }
   if (B > e->maxB) {
     MI_HIP(hipStreamSynchronize(e->stream));
-    hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats); hipFree(e->d_uniforms);
+    hipFree(e->d_next); hipFree(e->d_rowstats); hipFree(e->d_uniforms);      // (d_logprob / d_prob0 live in d_next's block)
     hipFree(e->d_topk_ids); hipFree(e->d_topk_lp);
-    MI_HIP(hipMalloc(&e->d_next, B * sizeof(int32_t)));
-    MI_HIP(hipMalloc(&e->d_logprob, B * sizeof(float)));
-    MI_HIP(hipMalloc(&e->d_prob0, B * sizeof(float)));
+    // tokens | logprobs | row-0 probabilities of a step in ONE block: one device-to-host copy per step instead of three
+    MI_HIP(hipMalloc(&e->d_next, (size_t)3 * B * sizeof(int32_t)));
+    e->d_logprob = (float*)(e->d_next + B);
+    e->d_prob0 = (float*)(e->d_next + 2 * B);
     MI_HIP(hipMalloc(&e->d_rowstats, 2 * B * sizeof(float)));
     MI_HIP(hipMalloc(&e->d_uniforms, B * sizeof(float)));
     MI_HIP(hipMalloc(&e->d_topk_ids, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(int32_t)));
     MI_HIP(hipMalloc(&e->d_topk_lp, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(float)));
     for (auto& s : e->slots) {
-      hipHostFree(s.tokens); hipHostFree(s.logprob); hipHostFree(s.prob0); hipHostFree(s.topk_ids); hipHostFree(s.topk_lp);
-      MI_HIP(hipHostMalloc(&s.tokens, B * sizeof(int32_t)));
-      MI_HIP(hipHostMalloc(&s.logprob, B * sizeof(float)));
-      MI_HIP(hipHostMalloc(&s.prob0, B * sizeof(float)));
+      hipHostFree(s.tokens); hipHostFree(s.topk_ids); hipHostFree(s.topk_lp);       // (logprob / prob0 live in tokens' block)
+      MI_HIP(hipHostMalloc(&s.tokens, (size_t)3 * B * sizeof(int32_t)));
+      s.logprob = (float*)(s.tokens + B);
+      s.prob0 = (float*)(s.tokens + 2 * B);
       MI_HIP(hipHostMalloc(&s.topk_ids, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(int32_t)));
       MI_HIP(hipHostMalloc(&s.topk_lp, (size_t)B * MI_MAX_TOP_LOGPROBS * sizeof(float)));
       if (!s.ev) MI_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
@@ -716,7 +718,7 @@ int forward_device(mi_engine* e, mi_kv* kv, int B, int L, bool all_pos, bool wan
   MI_TRY(kv_upload_table(kv, st));
 
   { Prof pr(e, "embed");
-    EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
+    EmbedCall ec{e->tok_src ? e->tok_src : e->d_tokens, (int)R, act, rndT, e->h};
     MI_TRY(launch_embed(e->embed.W, ec, st)); }
 
   const size_t layer_elems = kv_layer_elems(kv, d);
@@ -852,7 +854,7 @@ int forward_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const int32_t* l
   MI_TRY(kv_upload_table(kv, st));
 
   { Prof pr(e, "embed");
-    EmbedCall ec{e->d_tokens, (int)R, act, rndT, e->h};
+    EmbedCall ec{e->tok_src ? e->tok_src : e->d_tokens, (int)R, act, rndT, e->h};
     MI_TRY(launch_embed(e->embed.W, ec, st)); }
 
   const size_t layer_elems = kv_layer_elems(kv, d);
@@ -1064,10 +1066,10 @@ void mi_engine_destroy(mi_engine* e) {
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced); hipFree(e->d_gather);
   hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
   hipFree(e->sk_ws); hipFree(e->sk_ctr); hipFree(e->d_sq);
-  hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_logprob); hipFree(e->d_prob0); hipFree(e->d_rowstats);
+  hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
   for (auto& s : e->slots) {
-    hipHostFree(s.tokens); hipHostFree(s.logprob); hipHostFree(s.prob0); hipHostFree(s.topk_ids); hipHostFree(s.topk_lp);
+    hipHostFree(s.tokens); hipHostFree(s.topk_ids); hipHostFree(s.topk_lp);
     if (s.ev) hipEventDestroy(s.ev);
   }
   for (auto& p : e->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -1454,16 +1456,16 @@ int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, in
   MI_TRY(ensure_workspace(e, (size_t)B * L, (size_t)B, B));
   hipStream_t st = e->stream;
   if (tokens_in) MI_TRY(upload_tokens(e, tokens_in, B, L));
-  else MI_HIP(hipMemcpyAsync(e->d_tokens, e->d_next, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-  MI_TRY(forward_device(e, kv, B, L, false, true));
+  e->tok_src = tokens_in ? nullptr : e->d_next;            // (no copy: the sampler overwrites d_next only at the end of this step)
+  const int frc = forward_device(e, kv, B, L, false, true);
+  e->tok_src = nullptr;
+  MI_TRY(frc);
   MI_TRY(run_sample(e, B, sp));
   e->last_n = B;
   const int64_t t = e->next_ticket++;
   Slot& s = e->slots[t % NSLOT];
   s.B = B; s.topk = sp ? sp->top_logprobs : 0; s.ticket = t;
-  MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  MI_HIP(hipMemcpyAsync(s.logprob, e->d_logprob, B * sizeof(float), hipMemcpyDeviceToHost, st));
-  MI_HIP(hipMemcpyAsync(s.prob0, e->d_prob0, B * sizeof(float), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, ((size_t)2 * e->maxB + B) * sizeof(int32_t), hipMemcpyDeviceToHost, st));   // tokens | logprobs | row-0 probabilities
   if (s.topk > 0) {
     MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)B * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)B * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1489,16 +1491,16 @@ int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, co
   MI_TRY(ensure_workspace(e, (size_t)n * L, (size_t)n, std::max(n, kv->B)));
   hipStream_t st = e->stream;
   if (tokens_in) MI_TRY(upload_tokens(e, tokens_in, n, L));
-  else MI_HIP(hipMemcpyAsync(e->d_tokens, e->d_next, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-  MI_TRY(forward_device(e, kv, n, L, false, true, rows));
+  e->tok_src = tokens_in ? nullptr : e->d_next;
+  const int frc = forward_device(e, kv, n, L, false, true, rows);
+  e->tok_src = nullptr;
+  MI_TRY(frc);
   MI_TRY(run_sample(e, n, sp));
   e->last_n = n;
   const int64_t t = e->next_ticket++;
   Slot& s = e->slots[t % NSLOT];
   s.B = n; s.topk = sp ? sp->top_logprobs : 0; s.ticket = t;
-  MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  MI_HIP(hipMemcpyAsync(s.logprob, e->d_logprob, n * sizeof(float), hipMemcpyDeviceToHost, st));
-  MI_HIP(hipMemcpyAsync(s.prob0, e->d_prob0, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipMemcpyAsync(s.tokens, e->d_next, ((size_t)2 * e->maxB + n) * sizeof(int32_t), hipMemcpyDeviceToHost, st));   // tokens | logprobs | row-0 probabilities
   if (s.topk > 0) {
     MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)n * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)n * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
