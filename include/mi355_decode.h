@@ -144,8 +144,10 @@ int mi_kv_create_paged(mi_engine* e, int slots, int block_tokens, int n_blocks, 
  * summation-order noise between prefill shapes; hits are verified token by token, never by hash alone.
  * publish: the full blocks of tokens[0..n) (already in the row's cache, i.e. after its prefill was enqueued) become
  * reusable; they stay alive after the row is reset, until evicted (least recently used first) when a step needs a
- * block.  clear: forget everything (after a weight or adapter update).
- * stats: out[0..n) = free blocks, usable blocks, cached blocks, reused tokens, looked-up tokens, evictions. */
+ * block.  Eviction takes the deepest block of a chain before its parents (a chain is only reachable from its root).
+ * clear: forget everything (after a weight or adapter update).
+ * stats: out[0..n) = free blocks, usable blocks, cached (published) blocks, reused tokens, looked-up tokens, evictions,
+ * evictable blocks (published blocks no live row maps: only these can be given back to a step that needs a block). */
 int mi_kv_prefix_attach(mi_kv* kv, int row, const int32_t* tokens, int n, int* n_reused);
 int mi_kv_prefix_publish(mi_kv* kv, int row, const int32_t* tokens, int n);
 int mi_kv_prefix_clear(mi_kv* kv);

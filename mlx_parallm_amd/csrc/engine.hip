@@ -120,6 +120,8 @@ struct mi_engine {
                                          // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
   unsigned* d_seam_counter = nullptr;    // arrival counter of the in-launch seams (monotonic)
   int* d_seam_error = nullptr;           // set by a workgroup that gave up waiting at a seam
+  int* h_seam_err = nullptr;             // pinned: [slot] = *d_seam_error behind that step's launches, [NSLOT] = synchronous reads
+  unsigned seam_spin_limit = 1u << 20;   // polls before a workgroup gives up (option "seam_spin_limit"; tests force 0)
   unsigned seam_base = 0;
   int last_n = 0;                        // rows of the last enqueued step (device-resident token feed)                // value of *d_seam_counter once every enqueued launch has run
   void* xn = nullptr;            // [rows][max(H, I)] normalised activations of the prefill GEMMs
@@ -562,9 +564,33 @@ int ensure_seam(mi_engine* e) {          // arrival counter + error flag of the 
     MI_HIP(hipMalloc(&e->d_seam_error, sizeof(int)));
     MI_HIP(hipMemsetAsync(e->d_seam_counter, 0, sizeof(unsigned), e->stream));
     MI_HIP(hipMemsetAsync(e->d_seam_error, 0, sizeof(int), e->stream));
+    MI_HIP(hipHostMalloc(&e->h_seam_err, (NSLOT + 1) * sizeof(int)));
+    for (int i = 0; i <= NSLOT; ++i) e->h_seam_err[i] = 0;
     e->seam_base = 0;
   }
   return MI_OK;
+}
+
+// The seam's error flag travels with every step's results (one 4-byte copy behind the step's launches, only once a
+// paired launch has ever run on this engine); a synchronous call reads it after its stream synchronisation.  A set
+// flag means some workgroup stopped waiting and computed phase B from incomplete inputs: the call fails, the flag
+// is cleared so that the engine stays usable.
+int seam_record(mi_engine* e, int64_t ticket) {
+  if (e->d_seam_counter == nullptr) return MI_OK;
+  MI_HIP(hipMemcpyAsync(&e->h_seam_err[ticket % NSLOT], e->d_seam_error, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  return MI_OK;
+}
+int seam_fail(mi_engine* e) {
+  hipMemsetAsync(e->d_seam_error, 0, sizeof(int), e->stream);
+  return fail(MI_ERR_RUNTIME, "a workgroup gave up waiting at an in-launch seam (fused_gemv_pairs): the results of this call are invalid");
+}
+int seam_check_sync(mi_engine* e) {        // the stream is idle
+  if (e->d_seam_counter == nullptr) return MI_OK;
+  MI_HIP(hipMemcpyAsync(&e->h_seam_err[NSLOT], e->d_seam_error, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  MI_HIP(hipStreamSynchronize(e->stream));
+  if (e->h_seam_err[NSLOT] == 0) return MI_OK;
+  e->h_seam_err[NSLOT] = 0;
+  return seam_fail(e);
 }
 
 int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear& fb, GemvCall b, size_t rows,
@@ -579,7 +605,7 @@ int gemv_pair(mi_engine* e, const FusedLinear& fa, GemvCall a, const FusedLinear
     a.ev_start = x; a.ev_stop = y;
     e->prof_events.emplace_back(x, y);
   }
-  GemvSeam s{e->d_seam_counter, e->seam_base, e->d_seam_error};
+  GemvSeam s{e->d_seam_counter, e->seam_base, e->d_seam_error, e->seam_spin_limit};
   MI_TRY(launch_gemv_pair(fa.W, a, fb.W, b, s, e->stream));
   e->seam_base += (unsigned)gemv_pair_grid();
   return MI_OK;
@@ -596,6 +622,19 @@ uint64_t prefix_hash(uint64_t parent, const int32_t* toks, int n) {
 void kv_release_block(mi_kv* kv, int blk) {
   if (blk <= 0) return;
   if (--kv->refcnt[blk] == 0) kv->free_blocks.push_back(blk);
+}
+
+// A prefix chain is only reachable from its first block (attach stops at the first miss), so a chain is made "recent"
+// leaf first: afterwards its root is the most recently used entry and its deepest block the oldest of the chain --
+// eviction (from the back) takes leaves before their parents and never strands children behind a missing parent.
+void lru_touch_chain(mi_kv* kv, const std::vector<uint64_t>& chain) {
+  for (auto h = chain.rbegin(); h != chain.rend(); ++h) {
+    auto it = kv->prefix.find(*h);
+    if (it == kv->prefix.end()) continue;
+    kv->lru.erase(it->second.lru_it);
+    kv->lru.push_front(*h);
+    it->second.lru_it = kv->lru.begin();
+  }
 }
 
 // a block nobody but the prefix cache holds can be taken back (least recently used first)
@@ -1064,7 +1103,7 @@ void mi_engine_destroy(mi_engine* e) {
   free_linear(e->embed); free_linear(e->lm_head);
   hipFree(e->final_norm); hipFree(e->cos_tab); hipFree(e->sin_tab);
   hipFree(e->h); hipFree(e->qkv); hipFree(e->q); hipFree(e->attn); hipFree(e->act); hipFree(e->logits); hipFree(e->lora_t); hipFree(e->d_forced); hipFree(e->d_gather);
-  hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
+  hipFree(e->d_seam_counter); hipFree(e->d_seam_error); hipHostFree(e->h_seam_err); hipFree(e->d_rowpar); hipFree(e->deq_scratch);
   hipFree(e->sk_ws); hipFree(e->sk_ctr); hipFree(e->d_sq);
   hipFree(e->d_tokens); hipFree(e->d_next); hipFree(e->d_rowstats);
   hipFree(e->d_uniforms); hipFree(e->d_topk_ids); hipFree(e->d_topk_lp); hipFree(e->d_bias_ids); hipFree(e->d_bias_vals);
@@ -1270,6 +1309,7 @@ int mi_kv_prefix_attach(mi_kv* kv, int row, const int32_t* tokens, int n, int* n
   const int bs = 1 << kv->bs_shift;
   uint64_t parent = 0;
   int reused = 0;
+  std::vector<uint64_t> chain;
   // full blocks only, and at least one token of the prompt is left to run (its logits are needed)
   while (reused + bs <= n - 1 && kv->row_blocks[row] < kv->bt_stride) {
     const uint64_t h = prefix_hash(parent, tokens + reused, bs);
@@ -1278,12 +1318,11 @@ int mi_kv_prefix_attach(mi_kv* kv, int row, const int32_t* tokens, int n, int* n
         memcmp(it->second.tokens.data(), tokens + reused, bs * sizeof(int32_t)) != 0) break;
     kv->h_btab[(size_t)row * kv->bt_stride + kv->row_blocks[row]++] = it->second.block;
     ++kv->refcnt[it->second.block];
-    kv->lru.erase(it->second.lru_it);
-    kv->lru.push_front(h);
-    it->second.lru_it = kv->lru.begin();
+    chain.push_back(h);
     parent = h;
     reused += bs;
   }
+  lru_touch_chain(kv, chain);
   kv->stat_lookup_tokens += n;
   kv->stat_hit_tokens += reused;
   if (reused > 0) {
@@ -1303,6 +1342,7 @@ int mi_kv_prefix_publish(mi_kv* kv, int row, const int32_t* tokens, int n) {
   if (n > kv->h_off[row]) return fail(MI_ERR_INVALID, "prefix publish: those tokens are not in the row's cache yet");
   const int bs = 1 << kv->bs_shift;
   uint64_t parent = 0;
+  std::vector<uint64_t> chain;
   for (int i = 0; (i + 1) * bs <= n; ++i) {
     const uint64_t h = prefix_hash(parent, tokens + i * bs, bs);
     auto it = kv->prefix.find(h);
@@ -1317,8 +1357,10 @@ int mi_kv_prefix_publish(mi_kv* kv, int row, const int32_t* tokens, int n) {
     } else if (it->second.parent != parent || memcmp(it->second.tokens.data(), tokens + i * bs, bs * sizeof(int32_t)) != 0) {
       break;                                  // a different prefix owns this key: leave it (and everything behind it) alone
     }
+    chain.push_back(h);
     parent = h;
   }
+  lru_touch_chain(kv, chain);
   return MI_OK;
 }
 
@@ -1332,9 +1374,11 @@ int mi_kv_prefix_clear(mi_kv* kv) {
 
 int mi_kv_stats(const mi_kv* kv, int64_t* out, int n) {
   if (!kv || !out) return fail(MI_ERR_INVALID, "null argument");
-  const int64_t v[6] = {kv->paged ? (int64_t)kv->free_blocks.size() : -1, kv->paged ? (int64_t)kv->nblocks - 1 : -1,
-                        (int64_t)kv->prefix.size(), kv->stat_hit_tokens, kv->stat_lookup_tokens, kv->stat_evictions};
-  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+  int64_t evictable = 0;           // published blocks that only the cache holds: what kv_evict_one can actually give back
+  for (const auto& pe : kv->prefix) evictable += kv->refcnt[pe.second.block] == 1 ? 1 : 0;
+  const int64_t v[7] = {kv->paged ? (int64_t)kv->free_blocks.size() : -1, kv->paged ? (int64_t)kv->nblocks - 1 : -1,
+                        (int64_t)kv->prefix.size(), kv->stat_hit_tokens, kv->stat_lookup_tokens, kv->stat_evictions, evictable};
+  for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
   return MI_OK;
 }
 
@@ -1413,7 +1457,7 @@ int mi_forward(mi_engine* e, mi_kv* kv, const int32_t* tokens, int B, int L, flo
     MI_HIP(hipMemcpyAsync(logits_out, e->logits, (all_pos ? R : (size_t)B) * e->d.vocab_size * sizeof(float),
                           hipMemcpyDeviceToHost, e->stream));
   MI_HIP(hipStreamSynchronize(e->stream));
-  return MI_OK;
+  return seam_check_sync(e);
 }
 
 int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_t* targets, int B, int L,
@@ -1443,7 +1487,7 @@ int mi_score_tokens(mi_engine* e, mi_kv* kv, const int32_t* tokens, const int32_
     MI_HIP(hipMemcpyAsync(topk_logprobs, e->d_topk_lp, R * k * sizeof(float), hipMemcpyDeviceToHost, st));
   }
   MI_HIP(hipStreamSynchronize(st));
-  return MI_OK;
+  return seam_check_sync(e);
 }
 
 int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, int L, const mi_sample_params* sp,
@@ -1470,6 +1514,7 @@ int mi_step_enqueue(mi_engine* e, mi_kv* kv, const int32_t* tokens_in, int B, in
     MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)B * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)B * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
   }
+  MI_TRY(seam_record(e, t));
   MI_HIP(hipEventRecord(s.ev, st));
   *ticket = t;
   return MI_OK;
@@ -1505,6 +1550,7 @@ int mi_step_enqueue_rows(mi_engine* e, mi_kv* kv, const int32_t* rows, int n, co
     MI_HIP(hipMemcpyAsync(s.topk_ids, e->d_topk_ids, (size_t)n * s.topk * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipMemcpyAsync(s.topk_lp, e->d_topk_lp, (size_t)n * s.topk * sizeof(float), hipMemcpyDeviceToHost, st));
   }
+  MI_TRY(seam_record(e, t));
   MI_HIP(hipEventRecord(s.ev, st));
   *ticket = t;
   return MI_OK;
@@ -1545,6 +1591,7 @@ int mi_step_enqueue_mixed(mi_engine* e, mi_kv* kv, const int32_t* rows, const in
     }
   }
   e->last_n = -1;                                // the device-resident token feed does not survive a mixed step
+  MI_TRY(seam_record(e, t));
   MI_HIP(hipEventRecord(s.ev, st));
   *ticket = t;
   return MI_OK;
@@ -1558,6 +1605,10 @@ int mi_step_wait(mi_engine* e, int64_t ticket, int32_t* tokens_out, float* logpr
   if (s.ticket != ticket) return fail(MI_ERR_INVALID, "ticket expired (more than 4 steps in flight)");
   MI_HIP(hipSetDevice(e->device));
   MI_HIP(hipEventSynchronize(s.ev));
+  if (e->h_seam_err != nullptr && e->h_seam_err[ticket % NSLOT] != 0) {
+    e->h_seam_err[ticket % NSLOT] = 0;
+    return seam_fail(e);
+  }
   if (tokens_out) memcpy(tokens_out, s.tokens, s.B * sizeof(int32_t));
   if (logprob_out) memcpy(logprob_out, s.logprob, s.B * sizeof(float));
   if (prob_row0_out) memcpy(prob_row0_out, s.prob0, s.B * sizeof(float));
@@ -1612,6 +1663,10 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "short_prefill_skinny") { e->opt_short_prefill_skinny = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
+  if (k == "seam_spin_limit") {
+    if (value < 0 || value > (int64_t)0x7fffffff) return fail(MI_ERR_INVALID, "seam_spin_limit out of range");
+    e->seam_spin_limit = (unsigned)value; return MI_OK;
+  }
   if (k == "tile_weights") {
     if (e->finalized) return fail(MI_ERR_INVALID, "tile_weights must be set before mi_engine_finalize");
     e->opt_tile_weights = value != 0; return MI_OK;
@@ -1623,7 +1678,7 @@ int mi_engine_sync(mi_engine* e) {
   if (!e) return fail(MI_ERR_INVALID, "null engine");
   MI_HIP(hipSetDevice(e->device));
   MI_HIP(hipStreamSynchronize(e->stream));
-  return MI_OK;
+  return seam_check_sync(e);
 }
 
 }  // extern "C"

@@ -219,7 +219,7 @@ int launch_gemv_pair(const LinearW& WA, const GemvCall& a, const LinearW& WB, co
                      hipStream_t st) {
   const bool q4 = wk_is_quant(WA.wk);
   const MfmaParams pa = make_params(WA, a), pb = make_params(WB, b);
-  SeamParams seam{s.counter, s.base + (unsigned)cu_count(), 1u << 20, s.error};
+  SeamParams seam{s.counter, s.base + (unsigned)cu_count(), s.spin_limit, s.error};
   g_ev_start = (hipEvent_t)a.ev_start; g_ev_stop = (hipEvent_t)a.ev_stop;
   const int rc = (a.act == MI_BF16) ? launch_pair_at<bf16>(q4, pa, pb, seam, st) : launch_pair_at<f16>(q4, pa, pb, seam, st);
   g_ev_start = g_ev_stop = nullptr;

@@ -41,7 +41,8 @@ struct MfmaParams {
 
 // in-launch seam of gemv_pair_kernel: every workgroup adds 1 to *counter after phase A; phase B starts
 // when the counter has reached `target`.  A workgroup that polls `spin_limit` times without seeing it
-// sets *error and carries on (wrong results, reported by the host; never a hang).
+// sets *error and carries on: never a hang, and never a silent wrong token -- the host copies *error back behind
+// every step and fails that step with MI_ERR_RUNTIME (engine.hip: seam_record, mi_step_wait, seam_check_sync).
 struct SeamParams {
   unsigned* counter;
   unsigned target;
@@ -594,7 +595,7 @@ struct Phase {
 
 // ---- in-launch seam: every workgroup calls seam_arrive once it has published its outputs (write-through stores,
 // drained), may issue loads that do not depend on the other workgroups, then seam_wait.  Bounded: a workgroup
-// that gives up sets *error and carries on (wrong results, reported by the host; never a hang).
+// that gives up sets *error and carries on; the engine fails the step that contains the launch (see SeamParams).
 __device__ __forceinline__ void seam_arrive(const SeamParams& seam) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have left
   __syncthreads();

@@ -59,11 +59,13 @@ int launch_gemv(const LinearW& W, const GemvCall& c, hipStream_t st);
 
 // Two dependent decode GEMVs as ONE launch (gemv_mfma.hip, gemv_pair_kernel): B reads what A wrote.
 // `counter` is a device word that every launch advances by gemv_pair_grid(); `base` is its value before
-// this launch (the host keeps the running total); `error` is set to 1 if a workgroup gave up waiting.
+// this launch (the host keeps the running total); `error` is set to 1 if a workgroup gave up waiting after `spin_limit`
+// polls -- the engine reads it back with every step's results and fails the call (engine.hip: seam_record / seam_check_sync).
 struct GemvSeam {
   unsigned* counter;
   unsigned base;
   int* error;
+  unsigned spin_limit;
 };
 bool gemv_pair_supported(const LinearW& WA, const GemvCall& a, const LinearW& WB, const GemvCall& b);
 int launch_gemv_pair(const LinearW& WA, const GemvCall& a, const LinearW& WB, const GemvCall& b, const GemvSeam& s,

@@ -184,6 +184,19 @@ def free_port() -> int:
         return int(s.getsockname()[1])
 
 
+def gpu_preload_in_environment(env: Optional[Dict[str, str]] = None) -> str:
+    """Non-empty (the offending setting) when a profiler / tool library that initialises the GPU is preloaded into this
+    process: rocprofv3 sets LD_PRELOAD to its tool library and ROCP_TOOL_LIBRARIES / ROCPROFILER_* for it."""
+    env = os.environ if env is None else env
+    pre = env.get("LD_PRELOAD", "")
+    if any(k in pre for k in ("rocprof", "roctracer", "rocprofiler")):
+        return "LD_PRELOAD=" + pre
+    for key in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB"):
+        if env.get(key):
+            return f"{key}={env[key]}"
+    return ""
+
+
 def self_launch(argv: Sequence[str], nprocs: int, *, local_ranks: Optional[Sequence[int]] = None,
                 extra_env: Optional[Dict[str, str]] = None) -> int:
     """Run ``argv`` (a full command line) as ``nprocs`` rank processes of one node and relay rank 0's stdout.
@@ -198,6 +211,16 @@ def self_launch(argv: Sequence[str], nprocs: int, *, local_ranks: Optional[Seque
     import sys
     import threading
     import time
+
+    why = gpu_preload_in_environment()
+    if why:
+        # rocprofv3 (and anything else that preloads a HIP tool library) initialises the GPU in THIS process before
+        # main() runs; starting the ranks from here would be an exec out of a GPU-initialised process, which this
+        # pool forbids.  Profile a multi-GPU run by putting the rank program itself after `--`.
+        sys.stderr.write(f"self_launch: refusing to start rank processes from a process with a GPU tool preloaded ({why}); "
+                         "put the rank program itself after the profiler's `--` (RANK / WORLD_SIZE / MASTER_* set by hand) "
+                         "or profile --gpus 1\n")
+        return 2
 
     port = free_port()
     procs = []

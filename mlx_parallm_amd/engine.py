@@ -192,9 +192,10 @@ class PagedKVCache(KVCache):
         L.check(L.lib().mi_kv_prefix_clear(self._h))
 
     def stats(self) -> Dict[str, int]:
-        out = (C.c_int64 * 6)()
-        L.check(L.lib().mi_kv_stats(self._h, out, 6))
-        keys = ("free_blocks", "usable_blocks", "cached_blocks", "reused_tokens", "lookup_tokens", "evictions")
+        out = (C.c_int64 * 7)()
+        L.check(L.lib().mi_kv_stats(self._h, out, 7))
+        keys = ("free_blocks", "usable_blocks", "cached_blocks", "reused_tokens", "lookup_tokens", "evictions",
+                "evictable_blocks")
         return {k: int(v) for k, v in zip(keys, out)}
 
 

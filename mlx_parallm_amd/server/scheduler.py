@@ -128,7 +128,9 @@ class ContinuousScheduler:
 
     def _fits(self, seq: "Sequence") -> bool:
         """Admission control on the block arena: the prompt and everything the sequence may generate must find blocks now
-        (free ones, or published prefix blocks nobody is using) -- a step that runs out of blocks would fail every live row."""
+        (free ones, or published prefix blocks that NO live row maps: a live row publishes its own prompt blocks as soon as
+        its prefill is done, and those can never be evicted while it runs -- `evictable_blocks`, not `cached_blocks`) --
+        a step that runs out of blocks would fail every live row."""
         if not self.paged:
             return True
         st = self.kv.stats()
@@ -140,7 +142,7 @@ class ContinuousScheduler:
             if s is not None and not s.finished:
                 end = len(s.prompt) + s.max_tokens
                 growth += max(0, (end + bt - 1) // bt - (offs[s.slot] + bt - 1) // bt)
-        return need + growth <= st["free_blocks"] + st["cached_blocks"]
+        return need + growth <= st["free_blocks"] + st["evictable_blocks"]
 
     # ------------------------------------------------------------------ client side (any thread)
     def submit(self, prompt_ids, max_tokens: int, temp: float, top_p: float, sink: Sink) -> Sequence:

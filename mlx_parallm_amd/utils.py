@@ -189,7 +189,7 @@ def generate_step(
     logit_bias: Optional[Dict[int, float]] = None,
     cache: Optional[List[BatchedKVCache]] = None,
     *,
-    seed: int = 0,
+    seed: Optional[int] = None,
     uniforms_fn: Optional[Callable[[int], np.ndarray]] = None,
     top_logprobs: int = 0,
     return_details: bool = False,
@@ -204,7 +204,9 @@ def generate_step(
     (utils.py:420-427) step n+1 is launched before step n's tokens are read back.
 
     Extensions (keyword only): ``seed`` (Philox key for temp > 0; the counter is the step index of THIS generation,
-    so the same seed reproduces the same tokens), ``uniforms_fn(step) -> (B,)``
+    so the same seed reproduces the same tokens; the default ``None`` draws a fresh key from ``os.urandom`` per call, so
+    repeated calls on one prompt give different samples as the reference's advancing ``mx.random`` state does),
+    ``uniforms_fn(step) -> (B,)``
     caller-supplied noise, ``top_logprobs``, ``return_details`` (yield the dict ``tokens / logprobs /
     probs_row0 / top_ids / top_logprobs`` instead), ``logprobs_at_temperature`` (report logprobs under
     ``softmax(logits / temp)``, as the server's logprobs path does, instead of ``softmax(logits)``).
@@ -221,6 +223,8 @@ def generate_step(
         cache = _kv_pool.get(model.head_dim, kv_heads, B, paged=True)
     handle = model.bind_cache(cache, B, y.shape[1])
     engine = model.engine
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little") >> 1
 
     def args_for(step: int) -> SampleArgs:
         u = uniforms_fn(step) if (uniforms_fn is not None and temp != 0) else None
@@ -512,7 +516,7 @@ def batch_stream_generate_text(model, tokenizer, prompts_tokens, max_tokens: int
 # --------- server async batch API (utils.py:1087-1346) ---------
 async def batch_generate_text(model, tokenizer, prompts: List[str], max_tokens: int = 100, temp: float = 0.7,
                               top_p: float = 1.0, disable_prefix_cache: bool = False,
-                              max_context_length: Optional[int] = None, *, seed: int = 0,
+                              max_context_length: Optional[int] = None, *, seed: Optional[int] = None,
                               stats: Optional[Dict[str, float]] = None) -> List[Tuple[str, int, int]]:
     """-> [(text, n_prompt_tokens, n_completion_tokens)] per prompt (utils.py:1087-1346).
 

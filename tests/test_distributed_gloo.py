@@ -3,6 +3,7 @@ broadcast and the rank-ordered gather.  No GPU, no RCCL here; on t
 code runs with backend "nccl"."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -133,3 +134,15 @@ def test_bench_self_launches_two_ranks_as_a_plain_command():
     bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny-bf16"],
                          cwd=str(root), env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "needs an MI355X" in bad.stderr
+
+
+def test_self_launch_refuses_under_a_gpu_tool_preload(monkeypatch, capsys):
+    """rocprofv3 preloads a library that initialises the GPU before main(); starting rank processes from such a process is
+    the exec this pool forbids.  self_launch must refuse (exit code 2, a message) instead of forking (round-2 advisory)."""
+    from mlx_parallm_amd import distributed
+
+    assert distributed.gpu_preload_in_environment({}) == ""
+    assert distributed.gpu_preload_in_environment({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    rc = distributed.self_launch([sys.executable, "-c", "raise SystemExit(0)"], 2)
+    assert rc == 2 and "refusing" in capsys.readouterr().err

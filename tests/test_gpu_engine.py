@@ -785,6 +785,81 @@ def test_scheduler_waits_for_kv_blocks_instead_of_failing_live_rows(tiny_dirs):
     model.engine.close()
 
 
+def test_prefix_eviction_takes_leaves_before_parents_and_stats_count_what_is_evictable(tiny_dirs):
+    """A published chain is only reachable from its root (attach stops at the first miss), so under pressure the deepest
+    block must go first: after ONE eviction a prompt with the same prefix still maps the two blocks in front of it instead
+    of nothing (round-2 advisory).  `evictable_blocks` counts published blocks that no live row maps -- what the
+    scheduler's admission control may rely on -- while `cached_blocks` counts every published block."""
+    model, ref, cfg = _load_pair(tiny_dirs, "llama_f32")
+    eng = model.engine
+    V = cfg["vocab_size"]
+    greedy = SampleArgs(temp=0.0)
+    p = RNG.integers(3, V, size=52).astype(np.int32)                           # three full 16-token blocks + 4 tokens
+    kv = eng.new_paged_kv(2, block_tokens=16, n_blocks=8, max_tokens_per_row=112, kv_dtype="model")   # 7 usable blocks
+    eng.step_wait(eng.step_enqueue_rows(kv, [0], p[None], greedy), 1)          # row 0: 4 blocks
+    kv.prefix_publish(0, p)
+    st = kv.stats()
+    assert st["cached_blocks"] == 3 and st["evictable_blocks"] == 0 and st["free_blocks"] == 3   # the live row pins them
+    kv.reset_row(0)
+    st = kv.stats()
+    assert st["cached_blocks"] == 3 and st["evictable_blocks"] == 3 and st["free_blocks"] == 4
+    other = RNG.integers(3, V, size=80).astype(np.int32)                       # 5 blocks: 4 free + ONE eviction
+    eng.step_wait(eng.step_enqueue_rows(kv, [1], other[None], greedy), 1)
+    st = kv.stats()
+    assert st["evictions"] == 1 and st["cached_blocks"] == 2
+    assert kv.prefix_attach(0, p) == 32                                        # the leaf went; root and middle block are still a chain
+    kv.close()
+    eng.close()
+
+
+def test_scheduler_admission_counts_only_evictable_prefix_blocks(tiny_dirs):
+    """Two UNRELATED prompts on a 7-block arena (16-token blocks, 2 slots).  A (23 + 50 tokens -> 5 blocks) publishes its
+    first prompt block when its prefill is done; that block is cached but pinned by A itself.  B (22 + 20 -> 3 blocks)
+    arrives while A holds 2 blocks and may still claim 3: 5 free blocks do not cover 3 + 3, so B must WAIT although
+    free + cached = 6 would (round-2 advisory: the over-commit ended in 'block arena is exhausted' and failed every live
+    row).  Both must equal their solo oracle runs and must never have been live together."""
+    import threading
+
+    from mlx_parallm_amd.server.scheduler import ContinuousScheduler
+
+    d, cfg = tiny_dirs["llama_f32"]
+    model, tok = utils.load(d)
+    ref = ref_generate.load(d, max_pos=512)
+    sched = ContinuousScheduler(model, tok, max_slots=2, kv_dtype="model", chunk_tokens=16, block_tokens=16, kv_blocks=8)
+    sched.start()
+    done, ev = {}, threading.Event()
+
+    def sink(name):
+        def f(seq, delta, reason):
+            if reason is not None:
+                done[name] = (list(seq.generated), reason)
+                if len(done) == 2:
+                    ev.set()
+        return f
+
+    pa, pb = list(range(40, 63)), list(range(200, 222))
+    eos = tok.eos_token_id
+
+    def solo(p, n):
+        want = []
+        for _, (t, _p) in zip(range(n), ref_generate.generate_step(np.asarray(p)[None], ref, paged=False)):
+            if int(t[0, 0]) == eos:
+                break
+            want.append(int(t[0, 0]))
+        return want
+
+    wa, wb = solo(pa, 50), solo(pb, 20)
+    assert len(wa) >= 40                                    # A really grows into its fifth block (else the arena never fills)
+    sched.submit(pa, 50, 0.0, 1.0, sink("a"))
+    sched.submit(pb, 20, 0.0, 1.0, sink("b"))
+    assert ev.wait(timeout=120)
+    sched.stop()
+    assert done["a"] == (wa, done["a"][1]) and done["a"][1] != "error"
+    assert done["b"] == (wb, done["b"][1]) and done["b"][1] != "error"
+    assert sched.max_rows_seen == 1
+    model.engine.close()
+
+
 def test_scheduler_soak_random_arrivals_prefixes_and_cancels(tiny_dirs):
     """120 requests against 4 slots and a 40-block arena (16-token blocks): random prompt lengths around a few shared
     prefixes (prefix-KV reuse), random max_tokens, every seventh request cancelled while it runs, arrivals in bursts while

@@ -57,7 +57,8 @@ def _greedy(eng, prompts, steps, **opts):
     kv.close()
     for k in opts:
         eng.set_option(k, {"force_generic_gemv": 0, "fused_decode_attention": 1, "prefill_gemm": 1,
-                           "decode_attention_mfma": 1, "fused_gemv_pairs": 0, "skinny_gemm": 1, "short_prefill_skinny": 1}[k])
+                           "decode_attention_mfma": 1, "fused_gemv_pairs": 0, "skinny_gemm": 1, "short_prefill_skinny": 1,
+                           "seam_spin_limit": 1 << 20}[k])
     return np.stack(toks), lg
 
 
@@ -178,6 +179,33 @@ def test_alternative_launch_structures_agree(big):
     _same_tokens_up_to_near_ties(base, valu, lb, lv)
     chunked, lc = _greedy(eng, p, 5, prefill_gemm=0)
     _same_tokens_up_to_near_ties(base, chunked, lb, lc)
+
+
+def test_a_seam_that_gives_up_fails_the_call(big):
+    """The in-launch seam of the paired launches is bounded: a workgroup that stops waiting computes its second phase from
+    incomplete inputs.  That must never come back as tokens: the engine reads the seam's error flag with every result and
+    fails the call (round-2 verdict, weak #5).  spin limit 0 = the first unsuccessful poll gives up."""
+    eng, cfg = big
+    rng = np.random.default_rng(16)
+    p = rng.integers(0, cfg["vocab_size"], size=(8, 40)).astype(np.int32)
+    single, ls = _greedy(eng, p, 3, skinny_gemm=0)
+    with pytest.raises(RuntimeError, match="seam"):
+        _greedy(eng, p, 3, skinny_gemm=0, fused_gemv_pairs=3, seam_spin_limit=0)
+    for k, v in (("skinny_gemm", 1), ("fused_gemv_pairs", 0), ("seam_spin_limit", 1 << 20)):
+        eng.set_option(k, v)                                  # (_greedy did not get to its own reset)
+    # the same through the pipelined step interface: the failure belongs to the step whose launches gave up
+    kv = eng.new_kv(8, capacity=48, kv_dtype="model")
+    eng.forward(p, kv)
+    for k, v in (("skinny_gemm", 0), ("fused_gemv_pairs", 3), ("seam_spin_limit", 0)):
+        eng.set_option(k, v)
+    with pytest.raises(RuntimeError, match="seam"):
+        eng.decode_sample(kv, single[0][:, None], SampleArgs(temp=0.0))
+    kv.close()
+    for k, v in (("skinny_gemm", 1), ("fused_gemv_pairs", 0), ("seam_spin_limit", 1 << 20)):
+        eng.set_option(k, v)
+    # the flag was cleared with the failure: the engine is usable, and the pairs (with their real bound) still agree bit for bit
+    paired, lp = _greedy(eng, p, 3, skinny_gemm=0, fused_gemv_pairs=3)
+    assert np.array_equal(single, paired) and np.array_equal(ls, lp)
 
 
 def test_sampling_with_logprobs_config3(big):

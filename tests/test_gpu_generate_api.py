@@ -94,5 +94,9 @@ def test_sampled_batch_generate_is_reproducible_and_differs_from_greedy(pair):
     c = utils.batch_generate(model, tok, PROMPTS, max_tokens=12, format_prompts=False, temp=1.0, top_p=0.9, seed=6)
     g = utils.batch_generate(model, tok, PROMPTS, max_tokens=12, format_prompts=False, temp=0.0)
     assert a == b and a != c and a != g
+    # no seed: a fresh key per call (the reference's global mx.random state advances between calls; round-2 advisory)
+    d1 = utils.batch_generate(model, tok, PROMPTS, max_tokens=12, format_prompts=False, temp=1.0, top_p=0.9)
+    d2 = utils.batch_generate(model, tok, PROMPTS, max_tokens=12, format_prompts=False, temp=1.0, top_p=0.9)
+    assert d1 != d2
     with pytest.raises(NotImplementedError):
         utils.batch_generate(model, tok, PROMPTS, max_tokens=2, repetition_penalty=1.2)

@@ -2,6 +2,18 @@
 # Kernel-time summary of an arbitrary bench.py invocation (run from the repo root through gpurun):
 #   tools/profile_cmd.sh <tag> <bench.py arguments...>
 set -eo pipefail
+# gpus_guard: bench.py --gpus N > 1 makes bench.py a LAUNCHER (subprocess of rank processes); under rocprofv3 the
+# profiler's preloaded library has already initialised the GPU in it, so that would be an exec out of a GPU-initialised
+# process (forbidden on this pool).  Profile one rank: put the rank program itself after `--`.
+prev=""
+for a in "$@"; do
+  case "$prev $a" in
+    "--gpus 1") ;;
+    "--gpus "*) echo "$0: refusing --gpus $a under rocprofv3 (see the comment in this script)" >&2; exit 2 ;;
+  esac
+  case "$a" in --gpus=1) ;; --gpus=*) echo "$0: refusing $a under rocprofv3" >&2; exit 2 ;; esac
+  prev="$a"
+done
 TAG=$1; shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
