@@ -47,10 +47,113 @@ def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     return (round_bf16(x).view(np.uint32) >> 16).astype(np.uint16)
 
 
+# ---------------------------------------------------------------------------- accumulation envelope
+# The oracle proper ("exact") rounds the exactly summed value once.  MLX accumulates in float32 in an order it does not
+# document; so does every GPU kernel.  The two modes below redo every accumulation of the model (linears, RMSNorm
+# statistics, attention scores, softmax sum, P.V) with FLOAT32 accumulators in two different orders: partial sums of 32
+# consecutive terms (exact, rounded to float32 -- one matrix-core step) combined sequentially ("f32_seq32": a K loop)
+# or as a balanced tree ("f32_pairwise": split-K / tree reductions).  tests/golden/make_golden_wide.py runs both next
+# to the exact oracle and commits the spread; THAT spread -- evidence that involves no HIP kernel -- is the tolerance
+# of the production-width parity tests (tests/test_gpu_golden_wide.py).
+ACCUM_MODES = ("exact", "f32_seq32", "f32_pairwise")
+ACCUM = "exact"
+CHUNK = 32
+
+
+def set_accum(mode: str) -> None:
+    global ACCUM
+    if mode not in ACCUM_MODES:
+        raise ValueError(f"unknown accumulation mode {mode}")
+    ACCUM = mode
+
+
+class Accum:
+    """Float32 running combination of partial sums handed over in order: sequential, or a balanced tree built with a
+    binary-counter stack (equal-sized blocks are merged; leftovers smallest first) -- the same orders as
+    oracle/c/accum_gemm.c."""
+
+    def __init__(self, mode: str):
+        self.seq = mode == "f32_seq32"
+        self.acc = None
+        self.stack = []
+        self.n = 0
+
+    def add(self, part: np.ndarray) -> None:
+        part = np.asarray(part, dtype=np.float32)
+        if self.seq:
+            self.acc = part if self.acc is None else (self.acc + part).astype(np.float32)
+        else:
+            t = self.n
+            while t & 1:
+                part = (self.stack.pop() + part).astype(np.float32)
+                t >>= 1
+            self.stack.append(part)
+        self.n += 1
+
+    def result(self) -> np.ndarray:
+        if self.seq:
+            return self.acc
+        acc = self.stack[-1]
+        for blk in reversed(self.stack[:-1]):
+            acc = (blk + acc).astype(np.float32)
+        return acc
+
+
+def sum_last_f32(x: np.ndarray, mode: str) -> np.ndarray:
+    """Sum over the last axis with float32 accumulation in `mode` order (chunks of 32 summed exactly)."""
+    a = Accum(mode)
+    n = x.shape[-1]
+    for k0 in range(0, n, CHUNK):
+        a.add(x[..., k0:k0 + CHUNK].astype(np.float64).sum(axis=-1).astype(np.float32))
+    return a.result()
+
+
+_accum_lib = None
+
+
+def _accum_gemm_lib():
+    """oracle/c/accum_gemm.c (built by oracle/c/Makefile); None when it is not built -- the NumPy form below is the
+    same arithmetic, only slow at production widths."""
+    global _accum_lib
+    if _accum_lib is None:
+        import ctypes as C
+        from pathlib import Path
+
+        path = Path(__file__).resolve().parent / "_build" / "libaccum_gemm.so"
+        if not path.exists():
+            _accum_lib = False
+        else:
+            lib = C.CDLL(str(path))
+            lib.accum_gemm_nt.restype = None
+            lib.accum_gemm_nt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int]
+            _accum_lib = lib
+    return _accum_lib or None
+
+
+def matmul_nt_f32(x: np.ndarray, w: np.ndarray, mode: str, use_c: bool = True) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    K = x.shape[-1]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    lib = _accum_gemm_lib() if use_c else None
+    if lib is not None:
+        y = np.empty((x2.shape[0], w.shape[0]), np.float32)
+        lib.accum_gemm_nt(x2.ctypes.data, w.ctypes.data, y.ctypes.data, x2.shape[0], w.shape[0], K,
+                          0 if mode == "f32_seq32" else 1)
+        return y.reshape(*lead, w.shape[0])
+    a = Accum(mode)
+    for k0 in range(0, K, CHUNK):
+        a.add((x2[:, k0:k0 + CHUNK].astype(np.float64) @ w[:, k0:k0 + CHUNK].astype(np.float64).T).astype(np.float32))
+    return a.result().reshape(*lead, w.shape[0])
+
+
 def matmul_nt(x: np.ndarray, w: np.ndarray) -> np.ndarray:
     """x (..., K) @ w(N, K).T accumulated in float64, returned as float32.
 
     MLX's matmul / quantized_matmul accumulate in fp32; the oracle uses the exactly
     rounded value (fp64 accumulate, one rounding to fp32) so that it is independent of
-    any summation order."""
+    any summation order.  (Under set_accum("f32_...") -- the accumulation envelope, see above -- float32 accumulators.)"""
+    if ACCUM != "exact":
+        return matmul_nt_f32(x, w, ACCUM)
     return (np.asarray(x, dtype=np.float64) @ np.asarray(w, dtype=np.float64).T).astype(np.float32)

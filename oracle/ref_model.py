@@ -20,6 +20,7 @@ from typing import Dict, List, Optional
 
 import numpy as np
 
+from . import numerics
 from .numerics import matmul_nt, round_to
 from .ref_quant import dequantize
 
@@ -71,7 +72,7 @@ class Linear:
     def __call__(self, x: np.ndarray, xdt: str):
         """x @ W.T with fp32 accumulation; output dtype = result_type(x, W) (App. A.1)."""
         odt = promote(xdt, self.dtype)
-        y = round_to(matmul_nt(x, self.dense64()), odt)
+        y = round_to(matmul_nt(x, self.dense64() if numerics.ACCUM == "exact" else self.dense()), odt)
         if self.lora_a is not None:
             # y + (scale * ((x @ A) @ B)).astype(x.dtype)     (App. A.6)
             zdt = promote(xdt, self.lora_dtype)
@@ -97,6 +98,13 @@ class Linear:
 def rms_norm(x: np.ndarray, xdt: str, w: np.ndarray, wdt: str, eps: float):
     """w * cast_T(x32 * rsqrt(mean(x32^2) + eps)); out dtype result_type(x, w)  (App. A.2;
     llama.py:175-177,205; qwen3.py:42-43,127-130,159)."""
+    if numerics.ACCUM != "exact":                  # accumulation envelope (numerics.set_accum): float32 throughout
+        x32 = x.astype(np.float32)
+        ss = numerics.sum_last_f32(x32 * x32, numerics.ACCUM)[..., None]
+        rs32 = (np.float32(1.0) / np.sqrt(ss / np.float32(x.shape[-1]) + np.float32(eps))).astype(np.float32)
+        xn = round_to(x32 * rs32, xdt)
+        odt = promote(xdt, wdt)
+        return round_to(xn * w.astype(np.float32), odt), odt
     x64 = x.astype(np.float64)
     rs = 1.0 / np.sqrt(np.mean(x64 * x64, axis=-1, keepdims=True) + float(eps))
     xn = round_to((x64 * rs).astype(np.float32), xdt)
@@ -228,6 +236,8 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     Hkv = k.shape[1]
     rep = Hq // Hkv
     odt = promote(qdt, kdt)
+    if numerics.ACCUM != "exact":
+        return round_to(_sdpa_f32(q, k, v, scale, mask, numerics.ACCUM), odt), odt
     k = np.repeat(k, rep, axis=1).astype(np.float64)
     v = np.repeat(v, rep, axis=1).astype(np.float64)
     s = np.matmul(q.astype(np.float64), k.transpose(0, 1, 3, 2)) * float(scale)     # (B,H,L,S), float64 sums
@@ -238,6 +248,35 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     p = p / p.sum(axis=-1, keepdims=True)
     o = np.matmul(p, v).astype(np.float32)
     return round_to(o, odt), odt
+
+
+def _sdpa_f32(q, k, v, scale, mask, mode):
+    """The same attention with float32 accumulators (accumulation envelope, numerics.set_accum): scores = chunks of 32
+    head-dim products, softmax in float32 (max, exp, sum over chunks of 32 keys), P.V over chunks of 32 keys; per
+    (row, kv head) to bound memory.  Output float32 values, rounded to the output dtype by the caller."""
+    B, Hq, L, D = q.shape
+    Hkv, S = k.shape[1], k.shape[2]
+    G = Hq // Hkv
+    out = np.empty((B, Hq, L, D), np.float32)
+    CH = numerics.CHUNK
+    for b in range(B):
+        for h in range(Hkv):
+            qq = q[b, h * G:(h + 1) * G].astype(np.float32)                 # (G, L, D)
+            kk, vv = k[b, h].astype(np.float32), v[b, h].astype(np.float32)  # (S, D)
+            a = numerics.Accum(mode)
+            for d0 in range(0, D, CH):
+                a.add(np.matmul(qq[..., d0:d0 + CH].astype(np.float64), kk[:, d0:d0 + CH].astype(np.float64).T).astype(np.float32))
+            s = (a.result() * np.float32(scale)).astype(np.float32)        # (G, L, S)
+            if mask is not None:
+                s = (s + mask[b][None].astype(np.float32)).astype(np.float32)
+            s = s - s.max(axis=-1, keepdims=True)
+            p = np.exp(s.astype(np.float32)).astype(np.float32)
+            den = numerics.sum_last_f32(p, mode)[..., None]
+            a = numerics.Accum(mode)
+            for s0 in range(0, S, CH):
+                a.add(np.matmul(p[..., s0:s0 + CH].astype(np.float64), vv[s0:s0 + CH].astype(np.float64)).astype(np.float32))
+            out[b, h * G:(h + 1) * G] = (a.result() / den).astype(np.float32)
+    return out
 
 
 # --------------------------------------------------------------------------- model

@@ -9,6 +9,16 @@ BatchedKVCache = model dtype); batch 8 with a 1024-token prompt decoded to KV le
 including the second 256-key round of the split-KV decode attention), plus a batch-32 and a ragged batch-64 case
 (configs 4 and 5).  "parity unpinned": like every golden here these are outputs of the build's own oracle, not of MLX.
 
+Accumulation envelope (round 3; `--envelope`): next to every case, the same run TEACHER-FORCED with the exact oracle's
+tokens under the oracle's two float32-accumulating variants (oracle/numerics.py:set_accum -- chunks of 32 combined
+sequentially / as a balanced tree; linears through oracle/c/accum_gemm.c, RMSNorm / attention in NumPy).  Committed
+per case in tests/golden/envelope/<case>.npz: the variants' logprobs of the oracle's tokens and of its 8 largest
+logits, their arg-max ids, and a JSON summary (max / mean |logprob - exact|, seq32-vs-pairwise, id flips).  No HIP
+kernel is involved in these numbers: they are what summation order alone does to this model at these widths, and
+tests/test_gpu_golden_wide.py takes its tolerances from them (<= 1.5 x the committed spread).
+`--logits` additionally stores the exact oracle's FULL last-position logits of a few (step, row) pairs of the sampled
+case (config 3), against which the test checks the device's inverse-CDF draw.
+
 Checkpoints are NOT committed: tests/wide_models.py rebuilds them from seeds on either side.  Stored per case: the
 case spec (JSON), and per step the oracle's token ids, chosen-token logprobs, the 8 largest logits with their ids and
 the top1-top2 margin.  Run (about 40 min on 8 cores, < 40 GB):  python tests/golden/make_golden_wide.py [case ...]
@@ -63,6 +73,11 @@ CHECKPOINTS = {
              ragged=True, prompt_seed=117),
     ],
 }
+# int8 (north_star: "int4/int8-quantised weights"; nn.quantize with config["quantization"]["bits"] = 8, utils.py:679-690)
+CHECKPOINTS[("mistral-7b", "int8", 15)] = [
+    dict(name="wide_mistral_int8_modelkv", paged=False, **MAIN, prompt_seed=118),
+    dict(name="wide_mistral_int8_paged", paged=True, **MAIN, prompt_seed=119),
+]
 ADAPTER_SEED = 77
 
 
@@ -92,8 +107,116 @@ def run_case(ref, cfg, ck, case):
           f"margins <= 0.13: {int((np.stack(margins) <= 0.13).sum())} of {steps * B}", flush=True)
 
 
+FULL_LOGITS = {"wide_mistral_int4_topp_paged": [(0, 0), (0, 5), (1, 2), (7, 7), (12, 3), (23, 1)]}    # (step, row)
+
+
+def log_softmax64(lg):
+    x = lg.astype(np.float64)
+    x = x - x.max(axis=-1, keepdims=True)
+    return x - np.log(np.exp(x).sum(axis=-1, keepdims=True))
+
+
+def teacher_forced(ref, cfg, case, g, want_full=()):
+    """Feed the golden's tokens; -> per step: logprob of the golden token, logprobs at the golden's top-8 ids, arg-max id
+    (+ full logits of the (step, row) pairs in want_full)."""
+    B, steps = case["B"], case["steps"]
+    cache = ref.make_cache(B, paged=case["paged"])
+    y = wide_models.prompts_for(case, cfg["vocab_size"])
+    lp_tok, lp_top, amax, full = [], [], [], {}
+    T = np.float64(case["temp"]) if case["temp"] != 0 else np.float64(1.0)
+    for s in range(steps):
+        logits = ref(y, cache=cache, last_only=True)[:, -1, :]
+        lsm = log_softmax64(logits)                       # the sampler reports log_softmax(logits) (utils.py:345-364), not /temp
+        tok = g["tokens"][s].astype(np.int64)
+        lp_tok.append(lsm[np.arange(B), tok])
+        lp_top.append(np.take_along_axis(lsm, g["top_ids"][s].astype(np.int64), axis=-1))
+        amax.append(np.argmax(logits, axis=-1))
+        for (ss, b) in want_full:
+            if ss == s:
+                full[(s, b)] = logits[b].astype(np.float32)
+        y = tok[:, None]
+    return np.stack(lp_tok), np.stack(lp_top), np.stack(amax), full
+
+
+def run_envelope(ref, cfg, ck, case):
+    from oracle import numerics
+
+    path = OUT / f"{case['name']}.npz"
+    g = np.load(path)
+    B, steps = case["B"], case["steps"]
+    # the golden's own log-probabilities at its top-8 ids (log Z from the chosen token where it is among them, else recomputed)
+    res = {}
+    t0 = time.time()
+    for mode in ("f32_seq32", "f32_pairwise"):
+        numerics.set_accum(mode)
+        try:
+            res[mode] = teacher_forced(ref, cfg, case, g)
+        finally:
+            numerics.set_accum("exact")
+        print(f"  {case['name']} {mode}: {time.time() - t0:.0f} s", flush=True)
+    # exact reference values for the same quantities: chosen-token logprob is stored; top-8 logprobs = top_vals - logZ, with
+    # logZ recovered from the greedy rows (token = top-1) or re-derived from the variants' own gap (sampled rows: see below)
+    lp_exact = g["logprobs"].astype(np.float64)
+    greedy = case["temp"] == 0.0
+    out = dict(spec=str(g["spec"]))
+    summ = dict(case=case["name"], steps=steps, B=B)
+    for mode, (lp_tok, lp_top, amax, _f) in res.items():
+        d = np.abs(lp_tok - lp_exact)
+        summ[mode] = dict(max_lp=float(d.max()), mean_lp=float(d.mean()),
+                          id_flips=int((amax != g["top_ids"][:, :, 0]).sum()))
+        if greedy:
+            logz = g["top_vals"][:, :, 0].astype(np.float64) - lp_exact                   # token = top-1
+            top_exact = g["top_vals"].astype(np.float64) - logz[:, :, None]
+            summ[mode]["max_top8_lp"] = float(np.abs(lp_top - top_exact).max())
+        out[f"lp_{mode}"] = lp_tok.astype(np.float32)
+        out[f"top_lp_{mode}"] = lp_top.astype(np.float32)
+        out[f"argmax_{mode}"] = amax.astype(np.int32)
+    a, b = res["f32_seq32"], res["f32_pairwise"]
+    summ["seq32_vs_pairwise"] = dict(max_lp=float(np.abs(a[0] - b[0]).max()), mean_lp=float(np.abs(a[0] - b[0]).mean()),
+                                     max_top8_lp=float(np.abs(a[1] - b[1]).max()), id_diffs=int((a[2] != b[2]).sum()))
+    summ["oracle_margins_le_1e-2"] = int((g["margins"] <= 1e-2).sum())
+    out["summary"] = json.dumps(summ)
+    (OUT / "envelope").mkdir(exist_ok=True)
+    np.savez_compressed(OUT / "envelope" / f"{case['name']}.npz", **out)
+    print(f"envelope {json.dumps(summ)}", flush=True)
+
+
+def run_full_logits(ref, cfg, ck, case):
+    g = np.load(OUT / f"{case['name']}.npz")
+    pairs = FULL_LOGITS[case["name"]]
+    _a, _b, _c, full = teacher_forced(ref, cfg, case, g, want_full=pairs)
+    np.savez_compressed(OUT / f"{case['name']}_logits.npz", pairs=np.asarray(pairs, np.int32),
+                        logits=np.stack([full[tuple(p)] for p in pairs]), spec=str(g["spec"]))
+    print(f"{case['name']}: full logits of {len(pairs)} (step, row) pairs stored", flush=True)
+
+
 def main():
-    only = set(sys.argv[1:])
+    args = sys.argv[1:]
+    envelope, logits = "--envelope" in args, "--logits" in args
+    only = set(a for a in args if not a.startswith("--"))
+    if envelope or logits:
+        for ck, cases in CHECKPOINTS.items():
+            cases = [c for c in cases if (not only or c["name"] in only) and (envelope or c["name"] in FULL_LOGITS)]
+            if not cases:
+                continue
+            with tempfile.TemporaryDirectory() as d:
+                cfg = wide_models.build_checkpoint(d, *ck)
+                ref = ref_generate.load(d, max_pos=wide_models.MAX_POS)
+                adapted = False
+                for case in cases:
+                    if case.get("lora") and not adapted:
+                        ad = Path(d) / "adapter"
+                        wide_models.build_adapter(ad, cfg, ADAPTER_SEED)
+                        ref_generate.apply_adapters(ref.w, cfg["num_hidden_layers"], str(ad))
+                        adapted = True
+                    assert bool(case.get("lora")) == adapted, "adapter runs must come last"
+                    if logits and case["name"] in FULL_LOGITS:
+                        ref_model.CACHE_F64 = True
+                        run_full_logits(ref, cfg, ck, case)
+                        ref_model.CACHE_F64 = False
+                    if envelope:
+                        run_envelope(ref, cfg, ck, case)
+        return
     ref_model.CACHE_F64 = True
     for ck, cases in CHECKPOINTS.items():
         cases = [c for c in cases if not only or c["name"] in only]

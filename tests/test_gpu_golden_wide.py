@@ -30,13 +30,34 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import wide_models  # noqa: E402
+from oracle import ref_sample  # noqa: E402
 from mlx_parallm_amd import utils  # noqa: E402
 from mlx_parallm_amd.engine import SampleArgs  # noqa: E402
 
-WIDE = sorted((Path(__file__).resolve().parent / "golden").glob("wide_*.npz"))
+GOLD = Path(__file__).resolve().parent / "golden"
+WIDE = sorted(p for p in GOLD.glob("wide_*.npz") if not p.stem.endswith("_logits"))
+SERVING = sorted(GOLD.glob("serving_*.npz"))
 
+# Tolerances come from the ACCUMULATION ENVELOPE committed next to the goldens (tests/golden/envelope/<case>.npz, made by
+# make_golden_wide.py --envelope on the CPU): the oracle re-run with float32 accumulators in two summation orders.  What
+# summation order alone does to this model at these widths -- measured without any HIP kernel -- is the yardstick; the
+# device may deviate from the exact oracle by at most ENVELOPE_FACTOR x the larger of the two variants' deviations
+# (max and mean of |logprob - exact|, the same for the 8 largest logits), and may flip at most that many more greedy ids
+# than the worse variant did.  The absolute ceilings stay as a backstop.
+ENVELOPE_FACTOR = 1.5
 EXACT_MARGIN, EXACT_LP, EXACT_LP_MEAN = 1e-2, 2e-2, 1e-3
 MODELKV_MARGIN, MODELKV_LP = 0.13, 0.1
+
+
+def envelope_of(stem: str):
+    """-> dict(max_lp, mean_lp, max_top8_lp, id_flips) = the larger of the two float32-accumulating variants' deviations
+    from the exact oracle on this case, or None when the case has no committed envelope."""
+    f = GOLD / "envelope" / f"{stem}.npz"
+    if not f.exists():
+        return None
+    summ = json.loads(str(np.load(f)["summary"]))
+    a, b = summ["f32_seq32"], summ["f32_pairwise"]
+    return {k: max(a.get(k, 0.0), b.get(k, 0.0)) for k in ("max_lp", "mean_lp", "max_top8_lp", "id_flips")}
 
 
 class _Checkpoints:
@@ -85,7 +106,10 @@ def checkpoints(tmp_path_factory):
 
 
 def test_wide_golden_files_present():
-    assert len(WIDE) >= 17, "run tests/golden/make_golden_wide.py"
+    assert len(WIDE) >= 19, "run tests/golden/make_golden_wide.py"
+    assert len(SERVING) >= 4, "run tests/golden/make_golden_serving.py"
+    missing = [p.stem for p in WIDE if envelope_of(p.stem) is None]
+    assert not missing, f"run tests/golden/make_golden_wide.py --envelope {' '.join(missing)}"
 
 
 @pytest.mark.parametrize("path", WIDE, ids=[p.stem for p in WIDE])
@@ -101,10 +125,12 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
     margin_eps, lp_eps = (EXACT_MARGIN, EXACT_LP) if exact else (MODELKV_MARGIN, MODELKV_LP)
     y = prompts
     near, lp_err, top_err, decided, lp_sum, lp_n = 0, 0.0, 0.0, 0, 0.0, 0
+    drawn = []
     for s in range(steps):
         sp = SampleArgs(temp=spec["temp"], top_p=spec["top_p"], uniforms=None if greedy else g["uniforms"][s],
                         top_logprobs=8)
         res = model.engine.decode_sample(kv, y.astype(np.int32), sp)
+        drawn.append(res["tokens"].copy())
         want = g["tokens"][s]
         # the oracle's 8 largest logprobs: log Z from the chosen token's logit and logprob (greedy: the largest logit)
         for b in range(B):
@@ -131,11 +157,21 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
                         top_err = max(top_err, abs(dev[i] - (v - logz)))
         y = want[:, None]
     total = steps * B
+    env = envelope_of(path.stem)
     print(f"{path.stem}: mismatching ids {near}/{total} (oracle margins <= {margin_eps}: {int((g['margins'] <= margin_eps).sum())}), "
-          f"|logprob - oracle| max {lp_err:.2e} mean {lp_sum / max(lp_n, 1):.2e}, max top-8 logprob error {top_err:.2e}")
+          f"|logprob - oracle| max {lp_err:.2e} mean {lp_sum / max(lp_n, 1):.2e}, max top-8 logprob error {top_err:.2e}; "
+          f"CPU float32-accumulation envelope: {env}")
     assert lp_err <= lp_eps and top_err <= lp_eps, (path.stem, lp_err, top_err)
     if exact:
         assert lp_sum / max(lp_n, 1) <= EXACT_LP_MEAN, (path.stem, lp_sum / max(lp_n, 1))
+    if env is not None:
+        # the bound that does not come from the kernels under test
+        f = ENVELOPE_FACTOR
+        assert lp_err <= f * env["max_lp"], (path.stem, "max |logprob - exact|", lp_err, env)
+        assert lp_sum / max(lp_n, 1) <= f * env["mean_lp"], (path.stem, "mean |logprob - exact|", lp_sum / max(lp_n, 1), env)
+        if greedy:
+            assert top_err <= f * max(env["max_top8_lp"], env["max_lp"]), (path.stem, "top-8 logprobs", top_err, env)
+            assert near <= int(np.ceil(f * env["id_flips"])) + (0 if exact else 1), (path.stem, "greedy id flips", near, env)
     if exact and greedy:
         assert near <= 2, (path.stem, near, total)
     elif greedy:
@@ -150,5 +186,132 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
         # full size (tests/test_gpu_fullsize.py::test_sampling_with_logprobs_config3).  Here: the distribution (top-8 logprobs,
         # chosen-token logprobs on equal draws) must be the oracle's, and the draws must not be degenerate.
         assert near < total, (path.stem, near, total)
+        # ... and where the exact oracle's FULL logits are committed (wide_*_logits.npz: a few (step, row) pairs), the
+        # draw itself: the device's token must lie in the ORACLE's nucleus, and the caller's uniform must fall into that
+        # token's interval of the oracle's cumulative distribution up to DRAW_EPS -- the inverse-CDF position is only as
+        # sharp as the cumulative sum in front of it, which moves by the envelope's relative logprob error (a sum over the
+        # nucleus of p_i x |dlogp_i| <= max |dlogp|)
+        lf = path.with_name(path.stem + "_logits.npz")
+        assert lf.exists(), f"run tests/golden/make_golden_wide.py --logits {path.stem}"
+        full = np.load(lf)
+        draw_eps = max(2e-3, ENVELOPE_FACTOR * (env["max_lp"] if env else 2e-3))
+        worst = 0.0
+        for (ss, b), lg in zip(full["pairs"].tolist(), full["logits"]):
+            ids, pr = ref_sample.top_p_candidates(lg, spec["top_p"], spec["temp"])
+            tok = int(drawn[ss][b])
+            assert tok in set(ids.tolist()), (path.stem, ss, b, tok, "outside the oracle's nucleus")
+            j = int(np.where(ids == tok)[0][0])
+            c = np.cumsum(pr)
+            lo, hi, u = (float(c[j - 1]) if j > 0 else 0.0), float(c[j]), float(g["uniforms"][ss][b])
+            miss = max(lo - u, u - hi, 0.0)
+            worst = max(worst, miss)
+            assert miss <= draw_eps, (path.stem, ss, b, tok, (lo, hi), u)
+        print(f"{path.stem}: inverse-CDF position of the device's draws vs the oracle's distribution: worst miss {worst:.2e} "
+              f"(allowed {draw_eps:.2e}) over {len(full['pairs'])} (step, row) pairs")
     assert kv.offsets == [spec["L0"] + steps - 1] * B            # the prompt + (steps - 1) fed-back tokens
     kv.close()
+
+
+def _compare(tag, res_tok, res_lp, res_top, want, i, exact, stats):
+    """One sampled token of sequence `want` (a serving_* fixture's seq{n}_* arrays) at its index i."""
+    wt, margin = int(want["tokens"][i]), float(want["margins"][i])
+    margin_eps, lp_eps = (EXACT_MARGIN, EXACT_LP) if exact else (MODELKV_MARGIN, MODELKV_LP)
+    if int(res_tok) != wt:
+        assert margin <= margin_eps and int(res_tok) in want["top_ids"][i][:3].tolist(), (tag, i, int(res_tok), wt, margin)
+        stats["near"] += 1
+        return
+    stats["n"] += 1
+    err = abs(float(res_lp) - float(want["logprobs"][i]))
+    stats["lp"] = max(stats["lp"], err)
+    stats["lp_sum"] += err
+    assert err <= lp_eps, (tag, i, err)
+    logz = float(want["top_vals"][i][0]) - float(want["logprobs"][i])
+    dev = dict(zip(res_top[0].tolist(), res_top[1].tolist()))
+    for t, v in zip(want["top_ids"][i].tolist(), want["top_vals"][i].tolist()):
+        if t in dev:
+            stats["top"] = max(stats["top"], abs(dev[t] - (v - logz)))
+
+
+@pytest.mark.parametrize("path", SERVING, ids=[p.stem for p in SERVING])
+def test_serving_schedule_on_the_block_paged_arena_at_production_width(checkpoints, path):
+    """The kernels the continuous scheduler launches for BASELINE configs 4 / 5 -- attn_decode_mfma_kernel<.., 128, G, PAGED>,
+    attn_prefill_kernel<.., PAGED>, rope_append<PAGED>, and mi_step_enqueue_mixed over them -- at head_dim 128, G = 4 / 5,
+    64-token blocks and KV lengths that cross 1024, against the oracle's SOLO runs (tests/golden/make_golden_serving.py;
+    round-2 verdict, missing #2 / weak #4).  Teacher-forced with the oracle's tokens; same bars as the batch cases."""
+    g = np.load(path)
+    spec = json.loads(str(g["spec"]))
+    model, cfg = checkpoints.get(spec["family"], spec["precision"], spec["model_seed"], bool(spec.get("lora")),
+                                 spec["adapter_seed"])
+    eng, exact = model.engine, bool(spec["paged"])
+    rng = np.random.default_rng(spec["prompt_seed"])
+    prompts = [rng.integers(3, cfg["vocab_size"], size=n).astype(np.int32) for n in spec["prompt_lens"]]
+    seqs = [{k: g[f"seq{i}_{k}"] for k in ("tokens", "logprobs", "top_ids", "top_vals", "margins")} for i in range(4)]
+    steps, arrive, chunks, bt = spec["steps"], spec["arrive_step"], spec["chunks"], spec["block_tokens"]
+    blocks = sum((n + steps + 1 + bt - 1) // bt for n in spec["prompt_lens"]) + 2
+    kv = eng.new_paged_kv(4, block_tokens=bt, n_blocks=blocks, max_tokens_per_row=1024 + 2 * bt,
+                          kv_dtype="float32" if exact else "model")
+    greedy = SampleArgs(temp=0.0, top_logprobs=8)
+    stats = dict(near=0, n=0, lp=0.0, lp_sum=0.0, top=0.0)
+
+    def check(res, j, seq, idx):
+        _compare(path.stem, res["tokens"][j], res["logprobs"][j], (res["top_ids"][j], res["top_logprobs"][j]), seqs[seq], idx,
+                 exact, stats)
+
+    for r in range(3):                                        # prefill, one prompt per call (what admission does)
+        res = eng.step_wait(eng.step_enqueue_rows(kv, [r], prompts[r][None], greedy), 1, top_logprobs=8)
+        check(res, 0, r, 0)
+    fed3, off = 0, 0
+    for s in range(steps):
+        live = [0, 1, 2] + ([3] if s >= arrive + len(chunks) else [])
+        toks = [[int(seqs[r]["tokens"][s if r < 3 else s - (arrive + len(chunks))])] for r in live]     # teacher forcing
+        if arrive <= s < arrive + len(chunks):
+            n = chunks[s - arrive]
+            last = s == arrive + len(chunks) - 1
+            t = eng.step_enqueue_mixed(kv, live + [3], toks + [prompts[3][off:off + n].tolist()],
+                                       want=[1, 1, 1, 1 if last else 0], sample=greedy)
+            off += n
+            res = eng.step_wait(t, 4 if last else 3, top_logprobs=8)
+            if last:
+                check(res, 3, 3, 0)
+        else:
+            res = eng.step_wait(eng.step_enqueue_rows(kv, live, np.asarray(toks, np.int32), greedy), len(live), top_logprobs=8)
+        for j, r in enumerate(live):
+            check(res, j, r, s + 1 if r < 3 else s - (arrive + len(chunks)) + 1)
+    offs = kv.offsets
+    assert offs[:3] == [n + steps for n in spec["prompt_lens"][:3]] and offs[3] == spec["prompt_lens"][3] + steps - (arrive + len(chunks))
+    assert max(offs) > 1024 and kv.stats()["usable_blocks"] == blocks - 1
+    print(f"{path.stem}: {stats['n']} tokens compared, {stats['near']} near-tie flips, |logprob - oracle| max {stats['lp']:.2e} "
+          f"mean {stats['lp_sum'] / max(stats['n'], 1):.2e}, top-8 {stats['top']:.2e}")
+    assert stats["near"] <= (1 if exact else 4) and stats["top"] <= (EXACT_LP if exact else MODELKV_LP)
+    if exact:
+        assert stats["lp_sum"] / max(stats["n"], 1) <= EXACT_LP_MEAN
+    kv.close()
+
+
+@pytest.mark.parametrize("family,precision,seed,lora", [("mistral-7b", "bf16", 11, False), ("qwen3-14b", "int4", 14, True)])
+@pytest.mark.parametrize("kvd", ["model", "float32"])
+def test_block_paged_arena_is_bit_identical_to_contiguous_kv_at_production_width(checkpoints, family, precision, seed, lora, kvd):
+    """paged == contiguous, bit for bit, at head_dim 128 with G = 4 (Mistral) and G = 5 (Qwen3), 64-token blocks, a prompt of
+    1000 tokens (prefill attention over the block table) decoded across KV length 1024 (decode attention: second key round,
+    17th block) -- the instantiations test_paged_kv_is_bit_identical_to_contiguous_kv only covers at D = 16 / 64."""
+    model, cfg = checkpoints.get(family, precision, seed, lora, 77)
+    eng = model.engine
+    rng = np.random.default_rng(31)
+    p = rng.integers(3, cfg["vocab_size"], size=(3, 1000)).astype(np.int32)
+    steps = 30
+    flat = eng.new_kv(3, capacity=1000 + steps + 2, kv_dtype=kvd)
+    arena = eng.new_paged_kv(3, block_tokens=64, n_blocks=3 * 17 + 2, max_tokens_per_row=1088, kv_dtype=kvd)
+    la = eng.forward(p, flat)
+    greedy = SampleArgs(temp=0.0, top_logprobs=4)
+    ra = eng.step_wait(eng.step_enqueue_rows(arena, [0, 1, 2], p, greedy), 3, top_logprobs=4)
+    assert np.array_equal(np.argmax(la, axis=-1), ra["tokens"])
+    y = ra["tokens"][:, None].astype(np.int32)
+    for s in range(steps):
+        a = eng.decode_sample(flat, y, greedy)
+        b = eng.step_wait(eng.step_enqueue_rows(arena, [0, 1, 2], y, greedy), 3, top_logprobs=4)
+        for k in ("tokens", "logprobs", "top_ids", "top_logprobs"):
+            assert np.array_equal(a[k], b[k]), (family, kvd, s, k)
+        y = a["tokens"][:, None].astype(np.int32)
+    assert flat.offsets == arena.offsets == [1000 + steps] * 3
+    flat.close()
+    arena.close()

@@ -126,3 +126,53 @@ def test_logit_bias_applied_before_softmax():
     lg = np.zeros((1, 4), np.float32)
     s = ref_sample.sample(lg, temp=0.0, logit_bias={2: 5.0})
     assert s["tokens"][0, 0] == 2 and s["logprobs"][0] > np.log(0.9)
+
+
+# ---------------------------------------------------------------- accumulation envelope (oracle/numerics.py:set_accum)
+def test_float32_accumulation_variants_bracket_the_exact_oracle():
+    """The two float32-accumulating variants of the oracle (chunks of 32 combined sequentially / as a balanced tree) are
+    the SAME arithmetic as the exact one up to float32 summation order: the C kernel and its NumPy restatement agree bit
+    for bit, both stay within a few float32 ulps of the exactly rounded sums, and the two orders really differ."""
+    rng = np.random.default_rng(5)
+    x = numerics.round_bf16(rng.standard_normal((7, 4096 + 32)).astype(np.float32))
+    w = numerics.round_bf16(rng.standard_normal((53, 4096 + 32)).astype(np.float32) * 0.02)
+    exact = numerics.matmul_nt(x, w)
+    got = {}
+    for mode in ("f32_seq32", "f32_pairwise"):
+        c = numerics.matmul_nt_f32(x, w, mode)
+        n = numerics.matmul_nt_f32(x, w, mode, use_c=False)
+        assert np.array_equal(c, n), mode
+        assert np.abs(c - exact).max() <= 2e-6 * np.abs(exact).max() + 1e-6
+        got[mode] = c
+    assert not np.array_equal(got["f32_seq32"], got["f32_pairwise"])
+    # an odd number of chunks exercises the leftover path of the binary-counter tree
+    a = numerics.Accum("f32_pairwise")
+    parts = [np.float32(v) for v in (1.0, 2.0 ** -24, 2.0 ** -24, 1.0, 3.0)]
+    for p_ in parts:
+        a.add(np.asarray([p_], np.float32))
+    tree = np.float32(np.float32(np.float32(parts[0] + parts[1]) + np.float32(parts[2] + parts[3])) + parts[4])
+    assert a.result()[0] == tree
+    assert np.array_equal(numerics.sum_last_f32(np.ones((3, 100), np.float32), "f32_seq32"), np.full(3, 100, np.float32))
+
+
+def test_accumulation_modes_on_a_whole_model(tmp_path):
+    """set_accum switches every accumulation of the forward (linears, RMSNorm statistics, attention): logits of a small bf16
+    model under either float32 order stay within rounding noise of the exact oracle, and the switch is restored."""
+    from mlx_parallm_amd.tiny_model import build_tiny_model
+    from oracle import ref_generate
+
+    build_tiny_model(tmp_path, seed=2, vocab_size=300, hidden_size=128, layers=2, heads=4, kv_heads=2, intermediate_size=256,
+                     quantize_model=False, dtype="bfloat16", tie_word_embeddings=False, with_tokenizer=False)
+    ref = ref_generate.load(str(tmp_path), max_pos=64)
+    toks = np.random.default_rng(0).integers(0, 300, size=(2, 40))
+    exact = ref(toks, cache=ref.make_cache(2, paged=True))
+    for mode in ("f32_seq32", "f32_pairwise"):
+        numerics.set_accum(mode)
+        try:
+            got = ref(toks, cache=ref.make_cache(2, paged=True))
+        finally:
+            numerics.set_accum("exact")
+        assert np.abs(got - exact).max() <= 2e-2 and np.sqrt(((got - exact) ** 2).mean()) <= 2e-3, mode
+    assert numerics.ACCUM == "exact"
+    with pytest.raises(ValueError):
+        numerics.set_accum("f16")
