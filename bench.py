@@ -141,6 +141,125 @@ def streamed_weight_bytes(cfg, quant_bits):
     return params * bpp, params
 
 
+def numbers(cfg, quant_bits, B, K, W, ctx, leg, kv_dtype, kern, world):
+    """Algorithmic bytes and rates of one timed leg: the step, and the launches of linear `kern`."""
+    w_bytes, n_params = streamed_weight_bytes(cfg, quant_bits)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    D = cfg.get("head_dim") or H // nh
+    S_mid = ctx + W + K // 2
+    bpp = 2.0 if not quant_bits else quant_bits / 8.0 + 4.0 / 64.0
+    kvb = 2 if kv_dtype == "model" else 4
+    ab = 2 if kv_dtype == "model" else 4                    # activation bytes (float32 after layer 0 in PagedKVCache mode)
+    step_bytes = (w_bytes + B * cfg["num_hidden_layers"] * 2 * nkv * D * S_mid * kvb
+                  + B * cfg["num_hidden_layers"] * 2 * nkv * D * kvb + B * cfg["vocab_size"] * 4)
+    kern_bytes = {
+        "gemv_gate_up": 2 * I * H * bpp + B * H * ab + B * I * ab,
+        "gemv_down": I * H * bpp + B * I * ab + 2 * B * H * ab,
+        "gemv_qkv": (nh + 2 * nkv) * D * H * bpp + B * H * ab + B * (nh + 2 * nkv) * D * ab,
+        "gemv_o": H * nh * D * bpp + B * nh * D * ab + 2 * B * H * ab,
+        "gemv_head": cfg["vocab_size"] * H * bpp + B * H * ab + B * cfg["vocab_size"] * 4,
+    }.get(kern, 0.0)
+    ms_per_step = leg["elapsed"] / K * 1e3
+    avg_ms = leg["total_ms"] / max(leg["n_launch"], 1)
+    achieved = kern_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # prefill: algorithmic flops (SURVEY 8d) = 2 W T + NL 2 S^2 Hq D per sequence (causal), whatever the implementation
+    # spends on top (the float32 leg multiplies the exact three-way split of x: 3 x the MFMA work for the same flops)
+    pf_flops = B * (2.0 * n_params * ctx + cfg["num_hidden_layers"] * 2.0 * ctx * ctx * nh * D)
+    return dict(ms_per_step=ms_per_step, value=world * B * K / leg["elapsed"], step_bytes=step_bytes,
+                kern_bytes=kern_bytes, avg_ms=avg_ms, achieved=achieved,
+                prefill=world * B * ctx / leg["t_prefill"], pf_tflops=pf_flops / leg["t_prefill"] / 1e12, pf_flops=pf_flops,
+                rank_min=B * K / leg["own_max"], rank_max=B * K / leg["own_min"])
+
+
+def apply_lora(engine, cfg, layers, seed):
+    """A ~ U(-1/sqrt(K), 1/sqrt(K)), B ~ N(0, 0.01^2), rank 16, scale 10 (lora_init.py:68-72 defaults)."""
+    import torch
+
+    H, nh, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    D = cfg.get("head_dim") or H // nh
+    g = torch.Generator().manual_seed(seed + 99)
+    for li in range(cfg["num_hidden_layers"] - layers, cfg["num_hidden_layers"]):
+        for key, n in (("self_attn.q_proj", nh * D), ("self_attn.v_proj", nkv * D)):
+            a = (torch.rand((H, 16), generator=g) * 2 - 1) / (H ** 0.5)
+            b = torch.randn((16, n), generator=g) * 0.01
+            engine.set_lora(li, key, a, b, 10.0)
+
+
+OTHER_CONFIGS = [
+    # BASELINE.json configs 3 / 4 / 5 at their per-GPU shard (configs 4 / 5 shard 32 / 64 sequences over 4 / 8 GPUs by the
+    # sequence = 8 per GPU at full scale; the FULL batch on ONE GPU is the harder single-GPU statement and what the
+    # round-2 profiles measured, so that is what runs here)
+    dict(config="3: Mistral-7B int4-g64, batch 8, top-p 0.9 / T=1 sampling with logprobs", workload="mistral-7b-int4", batch=8,
+         lora=0, kv_modes=("model", "float32"), mixed=False),
+    dict(config="4: Qwen3-14B bf16, batch 32 (all of config 4's sequences on one GPU), greedy", workload="qwen3-14b-bf16",
+         batch=32, lora=0, kv_modes=("model",), mixed=False),
+    dict(config="5: Qwen3-14B int4-g64 + rank-16 LoRA on q/v of the last 8 layers, batch 64 (all of config 5's sequences on "
+                "one GPU), top-p sampling; decode steps, and mixed prefill + decode steps", workload="qwen3-14b-int4", batch=64,
+         lora=8, kv_modes=("model",), mixed=True),
+]
+
+
+def other_config_legs(args, seed):
+    """Short legs of the other BASELINE configurations, on the driver's clock: same timing protocol as the headline leg
+    (prefill untimed here, W warm-up + K timed steps, then K instrumented steps for the dominant linear)."""
+    import numpy as np
+
+    from mlx_parallm_amd.engine import Engine, SampleArgs
+
+    res = []
+    K, W, ctx = args.steps, min(args.warmup, 4), args.context
+    for oc in OTHER_CONFIGS:
+        family, prec = oc["workload"].rsplit("-", 1)
+        qb = {"int4": 4, "int8": 8}.get(prec, 0)
+        cfg = dict(SHAPES[family])
+        if qb:
+            cfg["quantization"] = {"group_size": 64, "bits": qb}
+        B = oc["batch"]
+        a = argparse.Namespace(**vars(args))
+        a.batch, a.warmup, a.no_prefill_timing, a.workload, a.lora = B, W, True, oc["workload"], oc["lora"]
+        chunk = max(16, (96 if qb == 4 else 256) - (B - 1) - 1)
+        cap = ctx + 2 * (K + W) + 2 * chunk + 136
+        t0 = time.perf_counter()
+        eng = Engine(cfg, device=0, max_positions=max(cap, 2048), act_dtype="bfloat16")
+        load_synthetic(eng, cfg, seed, qb, 0, 1, None)
+        if oc["lora"]:
+            apply_lora(eng, cfg, oc["lora"], seed)
+        t_load = time.perf_counter() - t0
+        rng = np.random.default_rng(seed + 23)
+        prompts = rng.integers(0, cfg["vocab_size"], size=(B, ctx)).astype(np.int32)
+        sample = SampleArgs(temp=1.0, top_p=0.9, seed=seed) if qb else SampleArgs(temp=0.0)
+        entry = {"config": oc["config"], "workload": oc["workload"], "batch_per_gpu": B, "context": ctx, "steps": K, "warmup": W,
+                 "load_seconds": round(t_load, 2)}
+        for kvm in oc["kv_modes"]:
+            leg = decode_leg(eng, cfg, a, kvm, prompts, sample, None, 1, cap)
+            n = numbers(cfg, qb, B, K, W, ctx, leg, kvm, "gemv_gate_up", 1)
+            entry["kv_" + ("model_dtype" if kvm == "model" else "float32")] = {
+                "value": round(n["value"], 2), "unit": "tokens/s", "ms_per_step": round(n["ms_per_step"], 4),
+                "step_bytes": int(n["step_bytes"]),
+                "step_hbm_frac": round(n["step_bytes"] / (n["ms_per_step"] * 1e-3) / 8e12, 4),
+                "roofline": {"bound": "hbm", "kernel": "gemv_gate_up", "achieved": round(n["achieved"], 1), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(n["achieved"] / 8000.0, 4), "traffic": None,
+                             "bytes_per_launch": int(n["kern_bytes"]), "avg_launch_ms": round(n["avg_ms"], 5),
+                             "launches": leg["n_launch"]},
+            }
+        if oc["mixed"]:
+            a.chunk, a.kv_dtype, a.mode = chunk, "model", "mixed"
+            m = mixed_leg(eng, cfg, a, sample, None, 1)
+            f, u = m["fused"], m["unfused"]
+            entry["mixed_prefill_decode"] = {
+                "what": f"{B - 1} live sequences decoding at KV length ~{ctx} while the next request's prompt enters {chunk} tokens "
+                        "per step in the same pass over the weights (mi_step_enqueue_mixed, block-paged KV)",
+                "value": round(f["decode_tokens"] / f["elapsed"], 2), "unit": "tokens/s (decode rows)",
+                "ms_per_step": round(f["elapsed"] / K * 1e3, 4),
+                "prefill_tokens_per_sec_in_the_same_steps": round(f["prompt_tokens"] / f["elapsed"], 1),
+                "fused_over_unfused": round(u["elapsed"] / f["elapsed"], 3),
+            }
+        eng.close()
+        res.append(entry)
+    return res
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +293,8 @@ def parse_args(argv=None):
     ap.add_argument("--chunk", type=int, default=0,
                     help="--mode mixed: prompt tokens ingested per step; 0 = what the live rows leave of 256 rows per step (int4: "
                          "96, the row limit of its weight-streaming kernel)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default workload only: skip the short legs of BASELINE configs 3 / 4 / 5 (`other_configs` of the line)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-process protocol without an engine (launch, rendezvous, bucketed weight "
                          "broadcast, barrier / max-over-ranks timing) -- the only mode that runs without a GPU; "
@@ -216,21 +337,23 @@ def decode_leg(engine, cfg, args, kv_dtype, prompts, sample, dist, world, cap):
     engine.step_wait(last, B)
     engine.sync()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                  # this rank's K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    own_min = own_max = own
     if world > 1:
         dev = "cuda" if args.backend == "nccl" else "cpu"
-        tt = torch.tensor([elapsed, t_prefill], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, t_prefill, own, -own], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, t_prefill = float(tt[0].item()), float(tt[1].item())
+        elapsed, t_prefill, own_max, own_min = float(tt[0].item()), float(tt[1].item()), float(tt[2].item()), -float(tt[3].item())
     engine.profile_select(args.profile_kernel)
     last = run_steps(K)
     engine.step_wait(last, B)
     n_launch, total_ms = engine.profile_read()
     engine.profile_select(None)
     kv.close()
-    return dict(elapsed=elapsed, t_prefill=t_prefill, n_launch=n_launch, total_ms=total_ms)
+    return dict(elapsed=elapsed, t_prefill=t_prefill, n_launch=n_launch, total_ms=total_ms, own_min=own_min, own_max=own_max)
 
 
 def mixed_leg(engine, cfg, args, sample, dist, world):
@@ -399,15 +522,7 @@ def main():
     t0 = time.perf_counter()
     load_synthetic(engine, cfg, args.seed, quant_bits, rank, world, dist, stats=bstats)
     if args.lora:
-        # A ~ U(-1/sqrt(K), 1/sqrt(K)), B ~ N(0, 0.01^2), rank 16, scale 10 (lora_init.py:68-72 defaults)
-        H, nh, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
-        D = cfg.get("head_dim") or H // nh
-        g = torch.Generator().manual_seed(args.seed + 99)
-        for li in range(cfg["num_hidden_layers"] - args.lora, cfg["num_hidden_layers"]):
-            for key, n in (("self_attn.q_proj", nh * D), ("self_attn.v_proj", nkv * D)):
-                a = (torch.rand((H, 16), generator=g) * 2 - 1) / (H ** 0.5)
-                b = torch.randn((16, n), generator=g) * 0.01
-                engine.set_lora(li, key, a, b, 10.0)
+        apply_lora(engine, cfg, args.lora, args.seed)
     t_load = time.perf_counter() - t0
 
     rng = np.random.default_rng(args.seed + 17 * rank)                 # each rank decodes its own shard
@@ -453,31 +568,10 @@ def main():
     H, I = cfg["hidden_size"], cfg["intermediate_size"]
     nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
     D = cfg.get("head_dim") or H // nh
-    S_mid = ctx + W + K // 2
-    bpp = 2.0 if not quant_bits else quant_bits / 8.0 + 4.0 / 64.0
     kern = args.profile_kernel
 
     def leg_numbers(leg, kv_dtype):
-        kvb = 2 if kv_dtype == "model" else 4
-        ab = 2 if kv_dtype == "model" else 4                    # activation bytes (float32 after layer 0 in PagedKVCache mode)
-        step_bytes = (w_bytes + B * cfg["num_hidden_layers"] * 2 * nkv * D * S_mid * kvb
-                      + B * cfg["num_hidden_layers"] * 2 * nkv * D * kvb + B * cfg["vocab_size"] * 4)
-        kern_bytes = {
-            "gemv_gate_up": 2 * I * H * bpp + B * H * ab + B * I * ab,
-            "gemv_down": I * H * bpp + B * I * ab + 2 * B * H * ab,
-            "gemv_qkv": (nh + 2 * nkv) * D * H * bpp + B * H * ab + B * (nh + 2 * nkv) * D * ab,
-            "gemv_o": H * nh * D * bpp + B * nh * D * ab + 2 * B * H * ab,
-            "gemv_head": cfg["vocab_size"] * H * bpp + B * H * ab + B * cfg["vocab_size"] * 4,
-        }.get(kern, 0.0)
-        ms_per_step = leg["elapsed"] / K * 1e3
-        avg_ms = leg["total_ms"] / max(leg["n_launch"], 1)
-        achieved = kern_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # prefill: algorithmic flops = 2 W T + NL 2 S^2 Hq D per sequence (causal), whatever the implementation
-        # spends on top (the float32 leg multiplies the exact three-way split of x: 3 x the MFMA work for the same flops)
-        pf_flops = B * (2.0 * n_params * ctx + cfg["num_hidden_layers"] * 2.0 * ctx * ctx * nh * D)
-        return dict(ms_per_step=ms_per_step, value=world * B * K / leg["elapsed"], step_bytes=step_bytes,
-                    kern_bytes=kern_bytes, avg_ms=avg_ms, achieved=achieved,
-                    prefill=world * B * ctx / leg["t_prefill"], pf_tflops=pf_flops / leg["t_prefill"] / 1e12, pf_flops=pf_flops)
+        return numbers(cfg, quant_bits, B, K, W, ctx, leg, kv_dtype, kern, world)
 
     def pmc_traffic(kv_dtype):
         """HBM bytes per launch of the dominant kernel.  NOT measured in this run: read from the committed PMC passes
@@ -537,6 +631,8 @@ def main():
                                  "what": "whole prefill call (B x context tokens, all kernels, host-timed) against the dense bf16 MFMA peak"},
             "load_seconds": round(t_load, 2),
             "ranks_seen": ranks_seen,
+            # each rank's own K steps, timed before it waits at the closing barrier: a slow rank shows here, not only in the max
+            "per_rank_tokens_per_sec": {"min": round(hn["rank_min"], 2), "max": round(hn["rank_max"], 2)},
         }
         out.update(bstats)
         if other is not None:
@@ -564,8 +660,13 @@ def main():
                            f"{steps_s} decode steps at KV length {ctx}, batch {B}, bf16 weights; block time scaled "
                            f"x{cfg['num_hidden_layers']}/{nl_s}; not MLX (unavailable offline)"),
             }
+        if world == 1 and not args.no_other_configs and args.workload == "mistral-7b-bf16" and B == 8 and not args.lora:
+            engine.close()
+            engine = None
+            out["other_configs"] = other_config_legs(args, args.seed)
         print(json.dumps(out), flush=True)
-    engine.close()
+    if engine is not None:
+        engine.close()
     if world > 1:
         dist.destroy_process_group()
 

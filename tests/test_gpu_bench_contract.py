@@ -48,6 +48,8 @@ def test_bench_gpus_2_as_a_plain_command_runs_two_ranks_with_engines():
     assert j["value"] > 0 and abs(j["value"] - 2 * 2 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 0.01
     assert "reference_numerics" in j and j["reference_numerics"]["value"] > 0
     assert "float32" in j["reference_numerics"]["what"]
+    pr = j["per_rank_tokens_per_sec"]                      # each rank's own K steps: min <= max, and the job total is at most the sum
+    assert 0 < pr["min"] <= pr["max"] and j["value"] <= 2 * pr["max"] * 1.01
 
 
 def test_dp_generate_two_ranks_equal_one_process(tiny_dirs, tmp_path):
