@@ -35,7 +35,7 @@
 #include <vector>
 #include <type_traits>
 
-#include "gemv_phase.h"
+#include "../gemv_phase.h"
 
 namespace mi {
 
@@ -107,7 +107,7 @@ struct SkinnyParams {
 // product is exact in the float32 accumulator, so the result is a float32 dot product in another summation order.
 // Outputs stay float32 with the run-time logical rounding `rnd` (layer 0 of that mode still rounds like the model).
 template <typename AT, int QB, int MT, bool SWIGLU, bool X32 = false>
-__global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT >= 5 || (X32 && QB == 8 && MT == 2)) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
+__global__ __launch_bounds__(SK_NW * 64, ((QB == 4 && !(MT == 2 && !X32)) || (QB == 8 && MT >= 3) || MT >= 5 || (X32 && QB == 8 && MT == 2)) ? 2 : 4) void skinny_kernel(const SkinnyParams p) {
   constexpr bool Q4 = QB == 4, Q8 = QB == 8, QUANT = QB != 0;
   static_assert(!X32 || MT <= 2, "float32 activations: 16- and 32-row instantiations");
   using XT = typename std::conditional<X32, float, AT>::type;
@@ -738,17 +738,12 @@ int skinny_mt(size_t rows) {
 
 struct SkinnyPlan { int ntiles, ngroups, nchunks, ksplit, mt, na, nslab; size_t ws_bytes; };
 
-// Row slabs (SkinnyParams::nslab): int4 weights above 32 rows can run as 32-row slabs, concurrently in one launch.
-// Measured (Qwen3-14B int4 + LoRA, 64 rows, same box): the linears with one accumulator stream (q|k|v, o, down: 112 VGPRs at
-// 32 rows, two workgroups per CU) gain ~6 % as slabs; the SwiGLU pair does not (148 VGPRs at 32 rows = one workgroup per
-// CU either way; capped at 128 it spills inside the loop): 76.9 us at 64 rows vs 82.9 (3 K slices) / 87.4 (2) / 92.1 (1) as
-// slabs.  So: slabs for the single-stream linears above 32 rows and for everything above 96 rows (where the 128-row
-// int4 SwiGLU instantiation would spill -- int4 used to stop at 96 rows).  MI_SKINNY_SLABS=0 / 2: never / always (A/B).
-static int skinny_slabs_mode() {
-  static const int v = [] { const char* e = getenv("MI_SKINNY_SLABS"); return e == nullptr ? 1 : atoi(e); }();
+// Row slabs (SkinnyParams::nslab): int4 weights above 32 rows run as 32-row slabs, concurrently in one launch.
+// MI_SKINNY_SLABS=0 restores the 48 / 64 / 96-row instantiations (A/B).
+static bool skinny_slabs_on() {
+  static const bool v = [] { const char* e = getenv("MI_SKINNY_SLABS"); return e == nullptr || atoi(e) != 0; }();
   return v;
 }
-static bool skinny_slabs_on() { return skinny_slabs_mode() != 0; }
 
 // ksplit: time of the launch ~ rounds x (bytes one workgroup moves) / (rate one CU gets), with the partial
 // tiles (written, then read once) counted as extra bytes.  A lone workgroup cannot pull more than ~40 GB/s
@@ -760,8 +755,7 @@ SkinnyPlan skinny_plan(const LinearW& W, const GemvCall& c, size_t rows) {
   pl.nslab = 1;
   {
     const bool q4w = wk_is_quant(W.wk) && !(W.wk == WK_Q8_BF16 || W.wk == WK_Q8_F16);
-    const bool want = skinny_slabs_mode() == 2 || (skinny_slabs_mode() == 1 && (pl.na == 1 || rows > 96));
-    if (q4w && c.act != MI_F32 && rows > 32 && want) { pl.mt = 2; pl.nslab = (int)((rows + 31) / 32); }
+    if (q4w && c.act != MI_F32 && rows > 32 && skinny_slabs_on()) { pl.mt = 2; pl.nslab = (int)((rows + 31) / 32); }
   }
   pl.ntiles = (c.epi == EPI_SWIGLU ? c.pair_offset : W.N) / 16;
   pl.ngroups = (pl.ntiles + SK_NW - 1) / SK_NW;

@@ -47,11 +47,9 @@ KINDS = [("bfloat16", "bf16"), ("float16", "f16"), ("bfloat16", "q4_bf16"), ("fl
     (64, 1040, 1024, 0),     # cost model's split, 65 tiles
     (33, 128, 384, 3),       # last chunk half full (K % 256 = 128)
     (80, 272, 1024, 2),      # 96-row fragments (6 tiles)
-    (128, 144, 768, 0),      # 128-row fragments (8 tiles; int4 stops at 96 rows)
+    (128, 144, 768, 0),      # 128-row fragments (8 tiles); int4: four 32-row slabs
 ])
 def test_store_matches_oracle_and_is_deterministic(act, kind, M, N, K, ksplit):
-    if M > 96 and kind.startswith("q4"):
-        pytest.skip("int4: up to 96 rows")
     ol, wdense, keep = _weight(kind, N, K)
     x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
     xd = dev(x, act)
@@ -267,8 +265,6 @@ def test_norm_handover_between_launches(tiny_dirs, name, B):
 @pytest.mark.parametrize("act,kind", KINDS)
 @pytest.mark.parametrize("M", [72, 120])
 def test_swiglu_above_64_rows(act, kind, M):
-    if M > 96 and kind.startswith("q4"):
-        pytest.skip("int4: up to 96 rows")
     I, K = 176, 768
     ol, wdense, keep = _weight(kind, 2 * I, K)
     x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
