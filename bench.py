@@ -578,10 +578,11 @@ def main():
         of this same command (profiles/, separate rocprofv3 --pmc runs, as the guide prescribes): 2 x FETCH_SIZE
         (gfx950 counts 64 B per 128-B request on wide coalesced streams, MI355X_MICROARCH.md HBM section) + WRITE_SIZE,
         both reported in KiB.  null for any other workload / kernel / batch than the one that was profiled."""
-        if args.workload != "mistral-7b-bf16" or kern != "gemv_gate_up" or B != 8 or kv_dtype != "model":
+        if args.workload != "mistral-7b-bf16" or kern != "gemv_gate_up" or B != 8 or args.lora:
             return None, None
-        want = "gemv_mfma_kernel<bf16,dense,MB=8,swiglu>"
-        for tag in ("round2", "round1"):
+        # model-dtype KV: the M <= 8 kernel with the fused RMSNorm; float32 KV: the split-K kernel on float32 activations
+        want = "gemv_mfma_kernel<bf16,dense,MB=8,swiglu>" if kv_dtype == "model" else "skinny_kernel<bf16,0,1,true,true>"
+        for tag in (("round3_bf16kv", "round2", "round1") if kv_dtype == "model" else ("round3_f32kv",)):
             vals = {}
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 f = ROOT / "profiles" / f"{tag}_pmc_{ctr}.csv"

@@ -434,6 +434,7 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
   if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {
     // prefill: one MFMA tile GEMM over all rows (the RMSNorm runs as its own row-wise kernel)
     Prof pr(e, prof);
+    const GemvCall c_in = c;                 // (the LoRA down-projection reads the caller's x and normalises on its own)
     if (c.act == MI_F32) {      // PagedKVCache mode: (norm +) exact three-way split of x, then the same tile GEMM over 3 K
       const size_t need = split3_bytes(rows, f.W.K);
       if (need > e->xs_cap) {
@@ -466,9 +467,10 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     }
     MI_TRY(launch_gemm_prefill(f.W, c, rows, e->stream, scratch, rows < 2048 ? e->gk_ws : nullptr, e->gk_cap));
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {   // y = T(y + T(scale (x A) B)) on the adapted columns
-      c.M = (int)rows;
-      MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
-      MI_TRY(launch_lora_up_add(f.W, c, e->lora_t, 128, e->stream));
+      GemvCall cl = c.act == MI_F32 ? c_in : c;
+      cl.M = (int)rows;
+      MI_TRY(launch_lora_down(f.W, cl, e->lora_t, 128, e->stream));
+      MI_TRY(launch_lora_up_add(f.W, cl, e->lora_t, 128, e->stream));
     }
     return MI_OK;
   }
@@ -477,6 +479,8 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     // (each row's arithmetic is that of a decode step, whatever the batch); the generic kernel took 8 rows per pass
     // over W.  A tile GEMM with the three-way split of x is the next step for this mode.
     Prof pr(e, prof);
+    const bool lora32 = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
+    if (lora32) { GemvCall cl = c; cl.M = (int)rows; MI_TRY(launch_lora_down(f.W, cl, e->lora_t, 128, e->stream)); }
     if (c.pro == PRO_NORM) {
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
       c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
@@ -514,6 +518,7 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       cc.x = x0 + r * (size_t)c.ldx * es_in;
       if (o0) cc.out = o0 + r * (size_t)c.ldo * es_out;
       if (r0) cc.resid = r0 + r * (size_t)c.ldo * es_in;
+      if (lora32) { cc.lora_t = e->lora_t + r * 128; cc.lora_t_ld = 128; }
       MI_TRY(launch_gemm_skinny(f.W, cc, (size_t)cc.M, e->stream, e->sk_ws, e->sk_ctr));
     }
     return MI_OK;

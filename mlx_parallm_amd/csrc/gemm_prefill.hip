@@ -798,7 +798,7 @@ bool gemm_prefill_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   // float32 activations on a bf16 model (PagedKVCache mode): x goes through launch_split3_rows first
   static const bool f32_ok = getenv("MI_GEMM_NO_F32") == nullptr;
   const bool x32 = f32_ok && c.act == MI_F32 && (W.wk == WK_BF16 || (W.wk == WK_Q4_BF16 && W.group == 64 && W.K % 128 == 0)) &&
-                   W.lora_b[0] == nullptr && W.lora_b[1] == nullptr && c.ldx % 4 == 0 && W.K % 4 == 0;
+                   c.ldx % 4 == 0 && W.K % 4 == 0;
   if (!dense && !q4 && !q8 && !x32) return false;
   if (W.K % BK != 0 || (!x32 && c.ldx % 8 != 0)) return false;
   if (c.epi == EPI_STORE_F32) return false;

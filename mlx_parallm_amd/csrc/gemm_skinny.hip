@@ -382,15 +382,24 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         float sc[NA], bb[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
+#ifdef MI_ABL_NOUNPACK      // timing-only ablation builds (tools/debug/build_ablation_libs.sh): results are wrong on purpose
+          wq[a][0] = u32x4{dw[a][sg * 2 + 0], dw[a][sg * 2 + 1], dw[a][sg * 2 + 0], dw[a][sg * 2 + 1]};
+          wq[a][1] = u32x4{dw[a][sg * 2 + 1], dw[a][sg * 2 + 0], dw[a][sg * 2 + 1], dw[a][sg * 2 + 0]};
+#else
           wq[a][0] = unpack_q4<AT>(dw[a][sg * 2 + 0]);
           wq[a][1] = unpack_q4<AT>(dw[a][sg * 2 + 1]);
+#endif
           sc[a] = (float)((const AT*)&sr[a][slot])[sg];
           bb[a] = (float)((const AT*)&br[a][slot])[sg] - Magic<AT>::offs * sc[a];
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int pb = ((i * 2 + sg) * 2) * 4 * MB + mt * 16;
+#ifdef MI_ABL_NOSX
+          const f32x4 sxv = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
           const f32x4 sxv = *(const f32x4*)(cur + NIMG * FRAG + ((i * 2 + sg) * MB + mt * 16 + g * 4) * 4);
+#endif
           f32x4 dq[NA];
 #pragma unroll
           for (int a = 0; a < NA; ++a) dq[a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -400,10 +409,18 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
             const u32x4 af1 = *(const u32x4*)(cur + img * FRAG + lane_off[1] + (pb + 4 * MB) * 16);
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
+#ifdef MI_ABL_NOFMA
+              acc[a][mt] = mfma16<AT>(af0, wq[a][0], acc[a][mt]);
+              acc[a][mt] = mfma16<AT>(af1, wq[a][1], acc[a][mt]);
+#else
               dq[a] = mfma16<AT>(af0, wq[a][0], dq[a]);
               dq[a] = mfma16<AT>(af1, wq[a][1], dq[a]);
+#endif
             }
           }
+#ifdef MI_ABL_NOFMA
+          continue;
+#endif
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
             const f32x4 d = dq[a];
@@ -490,7 +507,9 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         __builtin_amdgcn_sched_barrier(0);
         issue(slot, unit + UK);
         __builtin_amdgcn_sched_barrier(0);
+#ifndef MI_ABL_NOSTAGE
         if (i == UPC / 2) store_x(cn, nxt, cc + 1 < c1);   // (past the slice's end the last chunk is staged again, unused)
+#endif
       }
       __syncthreads();                            // the next chunk's fragments are complete; this chunk's are free
       unsigned char* t = cur; cur = nxt; nxt = t;
@@ -660,7 +679,22 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           const float sl = round_rt(gt * sig, p.rnd);
           o32[(size_t)m * p.ldo + n] = round_rt(sl * up, p.rnd);
         } else {
-          const float y = round_rt(y0, p.rnd);
+          float y = round_rt(y0, p.rnd);
+          if (p.lora_t != nullptr) {             // LoRALinear in this mode: y + T(scale (x A) B), the term in float32 (App. A.6)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+              const int r0 = sl ? p.lora_row0_1 : p.lora_row0_0;
+              const int ln = sl ? p.lora_n_1 : p.lora_n_0;
+              const int rk = sl ? p.lora_rank_1 : p.lora_rank_0;
+              const float* lb = sl ? p.lora_b1 : p.lora_b0;
+              if (lb != nullptr && n >= r0 && n < r0 + ln) {
+                const float* tt = p.lora_t + (size_t)m * p.lora_t_ld + sl * (p.lora_t_ld / 2);
+                float z = lora_dot(tt, lb + (n - r0), ln, rk);
+                z = round_rt((sl ? p.lora_scale_1 : p.lora_scale_0) * z, p.rnd);
+                y = round_rt(y + z, p.rnd);
+              }
+            }
+          }
           if (p.epi == EPI_RESID) {
             float* h = (float*)p.resid;
             float hv;
@@ -870,8 +904,9 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
     static const bool x32_ok = getenv("MI_SKINNY_NO_F32") == nullptr;
     const int n32 = c.epi == EPI_SWIGLU ? c.pair_offset : W.N;
     const bool wok = W.wk == WK_BF16 || (W.group == 64 && ((W.wk == WK_Q4_BF16 && W.K % 128 == 0) || (W.wk == WK_Q8_BF16 && W.K % 64 == 0)));
+    const bool lora = W.lora_b[0] != nullptr || W.lora_b[1] != nullptr;      // (the term is added in the plain-store epilogue)
     return x32_ok && wok && rows >= 1 && rows <= 32 && W.K % 32 == 0 && c.ldx % 4 == 0 && n32 % 16 == 0 &&
-           W.lora_b[0] == nullptr && W.lora_b[1] == nullptr;
+           (!lora || c.epi == EPI_STORE);
   }
   if (c.rnd != RND_NONE) return false;
   const bool q8 = ((W.wk == WK_Q8_BF16 && c.act == MI_BF16) || (W.wk == WK_Q8_F16 && c.act == MI_F16)) && W.group == 64 &&

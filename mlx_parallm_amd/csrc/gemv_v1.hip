@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256) void lora_up_add_kernel(GemvParams p, const fl
       float z = lora_dot(tt, lb + n, ln, rk);
       z = sc * z;
       AT* o = y + (size_t)m * ldy + r0 + n;
-      *o = (AT)((float)*o + (float)(AT)z);
+      if constexpr (sizeof(AT) == 4) *o = round_rt((float)*o + round_rt(z, p.rnd), p.rnd);   // float32 storage, logical rounding (layer 0 of the PagedKVCache mode)
+      else *o = (AT)((float)*o + (float)(AT)z);
     }
   }
 }
@@ -471,7 +472,8 @@ int launch_lora_up_add(const LinearW& W, const GemvCall& c, const float* t, int 
   switch (c.act) {
     case MI_BF16: hipLaunchKernelGGL(lora_up_add_kernel<bf16>, grid, block, 0, st, p, t, t_ld, (bf16*)c.out, c.ldo); break;
     case MI_F16: hipLaunchKernelGGL(lora_up_add_kernel<f16>, grid, block, 0, st, p, t, t_ld, (f16*)c.out, c.ldo); break;
-    default: return fail(MI_ERR_UNSUPPORTED, "lora_up_add: 16-bit activations only");
+    case MI_F32: hipLaunchKernelGGL(lora_up_add_kernel<float>, grid, block, 0, st, p, t, t_ld, (float*)c.out, c.ldo); break;
+    default: return fail(MI_ERR_UNSUPPORTED, "lora_up_add: bad activation dtype");
   }
   MI_HIP(hipGetLastError());
   return MI_OK;

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Timing-only ablation builds of gemm_skinny.hip (the guide's diagnostic loop, step 2: "ablate"): each build drops one
+# part of the int4 loop -- results are WRONG on purpose, only the launch time of the kernel is read.
+#   tools/debug/build_ablation_libs.sh        (in the build container; the .so files travel with the snapshot)
+set -e
+cd "$(dirname "$0")/../../mlx_parallm_amd/csrc"
+mkdir -p alt
+for A in NOFMA NOUNPACK NOSTAGE NOSX "NOFMA -DMI_ABL_NOUNPACK -DMI_ABL_NOSTAGE -DMI_ABL_NOSX"; do
+  tag=$(echo "$A" | tr -d ' ' | sed 's/-DMI_ABL_/_/g' | tr 'A-Z' 'a-z')
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMI_ABL_$A -c gemm_skinny.hip -o alt/gemm_skinny_abl_$tag.o &
+done
+wait
+for f in alt/gemm_skinny_abl_*.o; do
+  tag=$(basename $f .o | sed 's/gemm_skinny_abl_//')
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 engine.o gemv_v1.o gemv_mfma.o gemm_prefill.o $f attn.o attn_decode.o attn_prefill.o misc.o repack.o ops_api.o -o alt/libmi355_abl_$tag.so
+done
+ls -la alt/*.so

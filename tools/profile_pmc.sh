@@ -21,7 +21,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-second-leg --no-prefill-timing $*"
+CMD="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-other-configs --no-second-leg --no-prefill-timing $*"
 for CTR in $CTRS; do
   if timeout -k 10 300 rocprofv3 --pmc $CTR --output-format csv -d "$OUT/pmc_$CTR" -o run -- $CMD > "$OUT/pmc_$CTR.out" 2> "$OUT/pmc_$CTR.err"; then
     python3 "$ROOT/tools/summarize_prof.py" pmc "$OUT/pmc_$CTR" $CTR "$ROOT/gpurun_out/${TAG}_pmc_$CTR.csv" \

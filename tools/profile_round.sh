@@ -24,8 +24,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 export TMPDIR=/tmp
 cd /tmp
-STATS_CMD="python3 $ROOT/bench.py --steps 64 --warmup 8 --no-cpu-baseline $EXTRA"
-PMC_CMD="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-second-leg $EXTRA"
+STATS_CMD="python3 $ROOT/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-other-configs $EXTRA"
+PMC_CMD="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-other-configs --no-second-leg $EXTRA"
 
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $STATS_CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 python3 "$ROOT/tools/summarize_prof.py" stats "$OUT/stats" "$ROOT/gpurun_out/${TAG}_bench_kernel_stats.csv" \
