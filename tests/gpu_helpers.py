@@ -76,6 +76,30 @@ def gemv(ol: L.OpLinear, x, M, act, *, rnd=0, pro=0, norm_w=None, eps=0.0, epi=0
     return bool(used_mfma)
 
 
+def gemv_args(x, M, act, *, pro=0, norm_w=None, eps=0.0, epi=0, out=None, ldo=0, resid=None, pair_offset=0, ldx=None) -> L.OpGemvArgs:
+    a = L.OpGemvArgs()
+    a.x = x.data_ptr(); a.ldx = ldx if ldx is not None else x.shape[-1]; a.M = M
+    a.act = MIDT[act]; a.rnd = 0; a.pro = pro; a.epi = epi
+    a.norm_w = norm_w.data_ptr() if norm_w is not None else 0
+    a.eps = eps; a.ldo = ldo
+    a.out = out.data_ptr() if out is not None else 0
+    a.resid = resid.data_ptr() if resid is not None else 0
+    a.pair_offset = pair_offset; a.force_generic = 0
+    return a
+
+
+def chain(linears, args, wait_prev, iters=0):
+    """chain.hip on its own (mi_op_chain): -> (kernel give-up code, mean launch ms or None)."""
+    n = len(linears)
+    lp = (C.POINTER(L.OpLinear) * n)(*[C.pointer(ol) for ol in linears])
+    aa = (L.OpGemvArgs * n)(*args)
+    wp = (C.c_int32 * n)(*[int(w) for w in wait_prev])
+    ms, err = C.c_float(0.0), C.c_int32(0)
+    torch.cuda.synchronize()
+    L.check(L.lib().mi_op_chain(lp, aa, wp, n, int(iters), C.byref(ms), C.byref(err)))
+    return int(err.value), (ms.value if iters >= 1 else None)
+
+
 def attn_shape(B, L_, Hq, Hkv, D, act, kv, rnd, cap) -> L.OpAttnShape:
     s = L.OpAttnShape()
     s.B, s.L, s.Hq, s.Hkv, s.D, s.act, s.kv, s.rnd, s.cap = B, L_, Hq, Hkv, D, MIDT[act], MIDT[kv], rnd, cap
