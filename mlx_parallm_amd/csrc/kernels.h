@@ -79,6 +79,7 @@ int gemv_pair_grid();
 constexpr int CHAIN_CTR_WORDS = 4 * 8 * 32;
 bool chain_linear_ok(const LinearW& W, const GemvCall& c);
 int chain_grid();
+int chain_sq_ld(int K);          // row stride of the [8][ld] float table a residual linear leaves for the RMSNorm behind it (zeroed once)
 int launch_chain(const LinearW* const* W, const GemvCall* calls, const int* wait_prev, int nops, int M, int act,
                  unsigned* ctr, unsigned base, unsigned spin_limit, int* error, hipStream_t st);
 

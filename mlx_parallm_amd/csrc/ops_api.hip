@@ -120,8 +120,9 @@ int mi_op_chain(const mi_op_linear* const* w, const mi_op_gemv_args* a, const in
   // a normalised linear takes its row statistics from the residual epilogue in front of it (sums of h^2 per 16-column tile)
   for (int i = 1; i < nops; ++i) {
     if (c[i].pro == PRO_NORM && wp[i] && c[i - 1].epi == EPI_RESID && c[i - 1].resid == c[i].x && W[i - 1].N == W[i].K) {
-      MI_HIP(hipMalloc(&sq[i], (size_t)(W[i].K / 16) * 8 * sizeof(float)));
-      c[i - 1].sq_out = sq[i]; c[i].sq_in = sq[i]; c[i].sq_parts = W[i].K / 16;
+      MI_HIP(hipMalloc(&sq[i], (size_t)chain_sq_ld(W[i].K) * 8 * sizeof(float)));
+      MI_HIP(hipMemset(sq[i], 0, (size_t)chain_sq_ld(W[i].K) * 8 * sizeof(float)));
+      c[i - 1].sq_out = sq[i]; c[i].sq_in = sq[i]; c[i].sq_parts = chain_sq_ld(W[i].K);
     }
   }
   for (int i = 0; i < nops; ++i)

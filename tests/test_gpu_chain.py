@@ -79,31 +79,9 @@ def _run(linears, bufs, M, H, I, NQKV, dt, chained, iters=0):
     return res, ms
 
 
-@pytest.mark.parametrize("name,H,I,NQ,NQKV", [("mistral-7b", 4096, 14336, 4096, 6144), ("qwen3-14b", 5120, 17408, 5120, 7168),
-                                              ("small-ragged", 1024, 2560, 512, 1536)])
-@pytest.mark.parametrize("M", [8, 3])
-def test_chain_equals_the_single_launches(name, H, I, NQ, NQKV, M):
-    dt = "bfloat16"
-    linears, ws, bufs, keep = _block(H, I, NQ, NQKV, M, dt)
-    iters = 20 if M == 8 else 0
-    (h1, a1, q1), t1 = _run(linears, bufs, M, H, I, NQKV, dt, chained=False, iters=iters)
-    (h2, a2, q2), t2 = _run(linears, bufs, M, H, I, NQKV, dt, chained=True, iters=iters)
-    for nm, x, y in (("h", h1, h2), ("act", a1, a2), ("qkv", q1, q2)):
-        assert np.isfinite(y).all(), nm
-        d = np.abs(x - y)
-        tol = 2.0 ** -7 * np.maximum(np.abs(x), np.abs(y)) * 2 + 1e-3      # two bf16 ulps: one rounding flip on either side
-        frac = float((d > tol).mean())
-        print(f"{name} M={M} {nm}: max |chain - single| {d.max():.3e}, beyond 2 ulp: {frac:.2e}")
-        assert frac <= 2e-3 and d.max() <= 0.25 * max(1.0, float(np.abs(x).max())), (name, nm, d.max(), frac)
-    if iters:
-        print(f"{name}: four single launches {t1 * 1e3:.1f} us, one chain launch {t2 * 1e3:.1f} us")
-
-
-def test_chain_against_the_oracle_arithmetic():
-    """Small block, float64-exact reference of the same op sequence with the model's rounding points."""
-    dt, M, H, I, NQ, NQKV = "bfloat16", 5, 1024, 1536, 1024, 1536
-    linears, ws, bufs, keep = _block(H, I, NQ, NQKV, M, dt)
-    (h2, a2, q2), _ = _run(linears, bufs, M, H, I, NQKV, dt, chained=True)
+def _reference(ws, bufs, I, dt):
+    """float64-exact restatement of the four linears with the model's rounding points (the oracle's arithmetic for
+    llama.py:143,165,186-190), computed on the host from the same weights and inputs."""
     wo, wgu, wdn, wqkv = [host(w) for w in ws]
     attn, h0, post, inn = host(bufs["attn"]), host(bufs["h"]), host(bufs["post"]), host(bufs["inn"])
 
@@ -112,14 +90,52 @@ def test_chain_against_the_oracle_arithmetic():
         rs = 1.0 / np.sqrt((x64 * x64).mean(-1, keepdims=True) + 1e-5)
         return round_to(round_to((x64 * rs).astype(np.float32), dt) * w, dt)
 
-    h = round_to(h0 + round_to(matmul_nt(attn, wo), dt), dt)
-    xn = norm(h, post)
+    y = round_to(matmul_nt(attn, wo), dt)
+    h1 = round_to(h0 + y, dt)
+    xn = norm(h1, post)
     g, u = round_to(matmul_nt(xn, wgu[:I]), dt), round_to(matmul_nt(xn, wgu[I:]), dt)
     sig = round_to(1.0 / (1.0 + np.exp(-g.astype(np.float64))), dt)
     act = round_to(round_to(g * sig, dt) * u, dt)
-    h = round_to(h + round_to(matmul_nt(act, wdn), dt), dt)
-    q = round_to(matmul_nt(norm(h, inn), wqkv), dt)
-    for nm, want, got in (("h", h, h2), ("act", act, a2), ("qkv", q, q2)):
-        d = np.abs(want - got)
-        tol = 2.0 ** -7 * np.maximum(np.abs(want), np.abs(got)) * 2 + 2e-3
-        assert float((d > tol).mean()) <= 5e-3, (nm, d.max(), float((d > tol).mean()))
+    h2 = round_to(h1 + round_to(matmul_nt(act, wdn), dt), dt)
+    q = round_to(matmul_nt(norm(h2, inn), wqkv), dt)
+    return h2, act, q
+
+
+def _flip_stats(got, want, scale):
+    """A 16-bit rounding of a float32 sum taken in another order flips by one ulp now and then, and a flipped value feeds
+    everything behind it: count elements further than 2 bf16 ulps OF THE VALUES THAT WERE ADDED (scale) from the reference."""
+    d = np.abs(got - want)
+    tol = 2.0 ** -7 * 2 * np.maximum(np.abs(want), scale) + 1e-3
+    return float(d.max()), float((d > tol).mean())
+
+
+@pytest.mark.parametrize("name,H,I,NQ,NQKV", [("mistral-7b", 4096, 14336, 4096, 6144), ("qwen3-14b", 5120, 17408, 5120, 7168),
+                                              ("small-ragged", 1024, 2560, 512, 1536)])
+@pytest.mark.parametrize("M", [8, 3])
+def test_chain_equals_the_single_launches(name, H, I, NQ, NQKV, M):
+    """Both launch structures against the float64-exact reference: the chain must be as close to it as the single launches are
+    (same rounding points, another float32 summation order), at the production shapes and with ragged unit counts."""
+    dt = "bfloat16"
+    linears, ws, bufs, keep = _block(H, I, NQ, NQKV, M, dt)
+    iters = 20 if M == 8 else 0
+    single, t1 = _run(linears, bufs, M, H, I, NQKV, dt, chained=False, iters=iters)
+    chained, t2 = _run(linears, bufs, M, H, I, NQKV, dt, chained=True, iters=iters)
+    want = _reference(ws, bufs, I, dt)
+    for nm, w_, s_, c_, scale in zip(("h", "act", "qkv"), want, single, chained, (1.0, 0.05, 1.0)):
+        assert np.isfinite(c_).all(), nm
+        ms, fs = _flip_stats(s_, w_, scale)
+        mc, fc = _flip_stats(c_, w_, scale)
+        print(f"{name} M={M} {nm}: vs float64 reference -- single launches max {ms:.3e} / beyond 2 ulp {fs:.2e}; chain max {mc:.3e} / {fc:.2e}")
+        assert fc <= max(2.0 * fs, 2e-3) and mc <= max(2.0 * ms, 0.1), (name, nm, (ms, fs), (mc, fc))
+    if iters:
+        print(f"{name}: four single launches {t1 * 1e3:.1f} us, one chain launch {t2 * 1e3:.1f} us")
+
+
+def test_chain_against_the_oracle_arithmetic():
+    """Small block, ragged unit counts, 5 rows: the chain alone against the float64-exact reference."""
+    dt, M, H, I, NQ, NQKV = "bfloat16", 5, 1024, 1536, 1024, 1536
+    linears, ws, bufs, keep = _block(H, I, NQ, NQKV, M, dt)
+    got, _ = _run(linears, bufs, M, H, I, NQKV, dt, chained=True)
+    for nm, want, g_, scale in zip(("h", "act", "qkv"), _reference(ws, bufs, I, dt), got, (1.0, 0.05, 1.0)):
+        mx, frac = _flip_stats(g_, want, scale)
+        assert frac <= 5e-3, (nm, mx, frac)
