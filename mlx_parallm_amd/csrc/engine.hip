@@ -114,7 +114,7 @@ struct mi_engine {
   int opt_defer_norm = 1;       // float32 activations: RMSNorm row scale applied in the split-K kernel's epilogue (no norm launch)
   int opt_short_prefill_skinny = 1;   // short prefill / mixed calls on the weight-streaming kernel instead of the tile GEMM (gemv_rows)
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
-  bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0;
+  bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0, sq_ld = 0;
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
                                          // Off: measured on Mistral-7B bf16 B=8 the in-launch seam costs what the kernel
                                          // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
@@ -389,7 +389,9 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     // their neighbours (tests/test_gpu_fullsize.py).
     Prof pr(e, prof);
     // (float32 activations: the split-K kernel neither leaves nor takes the row statistics -- always the norm launch)
-    const bool handed = sq_was_valid && e->opt_norm_handover && c.act != MI_F32 && c.pro == PRO_NORM && rows <= 16 &&
+    c.M = (int)rows;
+    const int take_ld = (c.act != MI_F32 && c.pro == PRO_NORM) ? gemm_skinny_handover_ld(f.W, c, rows) : 0;
+    const bool handed = sq_was_valid && e->opt_norm_handover && take_ld > 0 && take_ld == e->sq_ld &&
                         e->sq_src == c.x && e->sq_K == f.W.K && c.ldx == f.W.K;
     c.M = (int)rows;
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {     // (normalises on its own when c.pro says so)
@@ -406,10 +408,11 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     }
     const size_t need = gemm_skinny_ws_bytes(f.W, c, rows);
     const int groups = gemm_skinny_groups(f.W, c, rows);
-    const bool produce = e->opt_norm_handover && c.act != MI_F32 && c.epi == EPI_RESID && rows <= 16 && groups <= 64 &&
-                         c.ldo == f.W.N;
+    const int tgroups = gemm_skinny_tile_groups(f.W, c, rows);
+    const int leave_ld = (c.act != MI_F32 && c.epi == EPI_RESID) ? gemm_skinny_handover_ld(f.W, c, rows) : 0;
+    const bool produce = e->opt_norm_handover && leave_ld > 0 && tgroups <= 64 && c.ldo == f.W.N;
     if (produce) {
-      if (!e->d_sq) MI_HIP(hipMalloc(&e->d_sq, (size_t)4096 * 16 * sizeof(float)));
+      if (!e->d_sq) MI_HIP(hipMalloc(&e->d_sq, (size_t)4096 * 16 * sizeof(float)));     // (64 tile groups x <= 128 rows fit eight times)
       c.sq_out = e->d_sq;
     }
     if (need > e->sk_ws_cap || groups > e->sk_ctr_cap) {
@@ -428,7 +431,7 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
       }
     }
     MI_TRY(launch_gemm_skinny(f.W, c, rows, e->stream, e->sk_ws, e->sk_ctr));
-    if (produce) { e->sq_valid = true; e->sq_src = c.resid; e->sq_parts = groups; e->sq_K = f.W.N; }
+    if (produce) { e->sq_valid = true; e->sq_src = c.resid; e->sq_parts = tgroups; e->sq_K = f.W.N; e->sq_ld = leave_ld; }
     return MI_OK;
   }
   if (e->opt_prefill_gemm && gemm_prefill_supported(f.W, c, rows)) {

@@ -64,8 +64,9 @@ struct SkinnyParams {
   const void* w; int N, K;
   int epi; void* out; int ldo; void* resid; int pair_offset;
   // RMSNorm hand-over between two launches of the 16-row instantiation (see "norm hand-over" in the kernel):
-  float* sq_out;                   // producer (residual epilogue): [tile groups][16] sums of h^2 over the group's 128 columns
+  float* sq_out;                   // producer (residual epilogue): [tile groups][sq_ld] sums of h^2 over the group's 128 columns
   const float* sq_in; int sq_parts;   // consumer: the producer's partial sums and their count
+  int sq_ld;                       // rows of the table, padded: slabs x rows per workgroup (16 / 32 / 64 rows per workgroup only)
   const void* norm_w; float eps;   //           x -> w * T(x * rsqrt(mean(x^2) + eps)) while staging
   int rnd;                         // float32 activations: logical rounding of the outputs (RND_*)
   // float32 activations, RMSNorm in front (X32 instantiations only): y = rs[m] * sum_k (x[m][k] w_norm[k]) W[n][k] -- the
@@ -205,9 +206,15 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // down_proj): its epilogue leaves sum(h^2) per row and tile group next to h, and the consumer turns those 32..40
   // partial sums into rsqrt(mean + eps) and normalises while it stages x -- no launch for the norm, no second pass
   // over x.  (Letting every workgroup compute the statistics itself from x was measured slower than the launch.)
-  __shared__ float rs_sh[16];
-  __shared__ float sqp_sh[SK_NW * 16];
-  const bool norm = (MT == 1) && p.sq_in != nullptr;
+  // 16- and 32-row workgroups.  Measured per batch size (same box, norm_handover 1 vs 0): 8 rows int4 +2.6 %, 32 rows bf16
+  // +1.8 % (Qwen3-14B) / +3.2 % (Mistral-7B), int4 +-0; the 64-row form was built too and LOST 3 % (bf16) / 6.5 % (int4 + LoRA):
+  // eight table loads per thread at the head and the normalisation of four pieces per chunk inside a loop that is already
+  // bound by its vector instructions -- above 32 rows the separate norm launch stays.
+  constexpr bool NH = !X32 && (MT == 1 || MT == 2);
+  constexpr int MBC = MB < 64 ? MB : 64;
+  __shared__ float rs_sh[NH ? MB : 16];
+  __shared__ float sqp_sh[SK_NW * (NH ? MBC : 16)];
+  const bool norm = NH && p.sq_in != nullptr;
   u32x4 xr[MT], xw[MT], xr2[X32 ? MT : 1], xnw[X32 ? MT : 1], xnw2[X32 ? MT : 1];
   float sqacc[X32 ? MT : 1];
 #pragma unroll
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           xnw2[i] = *(const u32x4*)((const float*)p.norm_w + (k < p.K ? k : 0) + 4);
         }
       }
-      if constexpr (MT == 1) {
+      if constexpr (NH) {
         if (norm) xw[i] = *(const u32x4*)((const AT*)p.norm_w + (k < p.K ? k : 0));
       }
     }
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         continue;
       }
       u32x4 v = ok ? xr[i] : u32x4{0u, 0u, 0u, 0u};
-      if constexpr (MT == 1) {
+      if constexpr (NH) {
         if (norm) {
           AT* e = (AT*)&v;
           const AT* we = (const AT*)&xw[i];
@@ -441,13 +448,17 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // norm hand-over: ALL the producer's partial sums in one round trip (512 threads, <= 2 loads each), issued FIRST so that
   // waiting for them leaves the activation and weight loads in flight.  (The former 16-thread loop paid one L2 / memory
   // round trip per 8 parts behind the weight loads, which made the hand-over a wash.)  Straight-line: no load under a branch.
-  constexpr int SQ_LD = MT == 1 ? SQ_PARTS_MAX * 16 / (SK_NW * 64) : 1;
+  // thread t holds parts t / MB + (512 / MB) u of row t mod MB (table [part][sq_ld], this workgroup's rows at row0)
+  constexpr int SQ_LD = NH ? SQ_PARTS_MAX * MB / (SK_NW * 64) : 1;
+  constexpr int SQ_STEP = NH ? (SK_NW * 64) / MB : 1;
   float pv[SQ_LD];
-  if constexpr (MT == 1) {
+  if constexpr (NH) {
     const float* sqsrc = norm ? p.sq_in : (const float*)p.x;
-    const int nsq = norm ? p.sq_parts * 16 : 1;     // host: sq_parts <= SQ_PARTS_MAX
 #pragma unroll
-    for (int u = 0; u < SQ_LD; ++u) pv[u] = sqsrc[min(tid + u * (SK_NW * 64), nsq - 1)];
+    for (int u = 0; u < SQ_LD; ++u) {
+      const int part = tid / MB + SQ_STEP * u;
+      pv[u] = sqsrc[(norm && part < p.sq_parts) ? part * p.sq_ld + row0 + tid % MB : 0];      // host: sq_parts <= SQ_PARTS_MAX
+    }
   }
   load_x(c0);
 #pragma unroll
@@ -465,21 +476,21 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       for (int r = 0; r < 4; ++r)
         hpre[mt * 4 + r] = (float)hp[(size_t)(row0 + min(mt * 16 + g * 4 + r, Mloc - 1)) * p.ldo + tile * 16 + c16];
   }
-  if constexpr (MT == 1) {
+  if constexpr (NH) {
     if (norm) {
-      // thread t holds parts (t >> 4) + 32 u of row t & 15: a fixed tree -- the two registers, lanes +16 / +32 of the wave
-      // (4 parts), then the 8 waves through LDS
+      // a fixed tree: the thread's registers in order, the lanes of the wave that hold the same row (16 rows: +16 / +32;
+      // 32 rows: +32), then the 8 waves through LDS (64 rows: wave w holds the parts 8 u + w of every row)
       float v = 0.f;
 #pragma unroll
-      for (int u = 0; u < SQ_LD; ++u) v += (tid + u * (SK_NW * 64) < p.sq_parts * 16) ? pv[u] : 0.f;
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      if (lane < 16) sqp_sh[wave * 16 + lane] = v;
+      for (int u = 0; u < SQ_LD; ++u) v += (tid / MB + SQ_STEP * u < p.sq_parts) ? pv[u] : 0.f;
+      if constexpr (MB == 16) v += __shfl_xor(v, 16);
+      if constexpr (MB <= 32) v += __shfl_xor(v, 32);
+      if (lane < MBC) sqp_sh[wave * MBC + lane] = v;
       __syncthreads();
-      if (tid < 16) {
+      if (tid < MB) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < SK_NW; ++w) t += sqp_sh[w * 16 + tid];
+        for (int w = 0; w < SK_NW; ++w) t += sqp_sh[w * MBC + tid];
         rs_sh[tid] = 1.0f / sqrtf(t / (float)p.K + p.eps);
       }
       __syncthreads();
@@ -639,13 +650,15 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
     }
   }
   SK_STAMP(6);
-  const bool want_sq = (MT == 1) && p.sq_out != nullptr;      // (uniform; then spare waves stay for the barriers below)
+  const bool want_sq = NH && p.sq_out != nullptr;      // (uniform; then spare waves stay for the barriers below)
   if (!valid && !want_sq) return;
 
   // ================= epilogue: lane (c16, g) holds y[16 mt + 4 g + r][16 tile + c16]
   const int n = tile * 16 + c16;
   AT* out = (AT*)p.out;
-  float hsq[4] = {0.f, 0.f, 0.f, 0.f};
+  float hsq[NH ? MT * 4 : 1];
+#pragma unroll
+  for (int i = 0; i < (NH ? MT * 4 : 1); ++i) hsq[i] = 0.f;
   // residual epilogue above 16 rows: ALL of the lane's h values in one round trip.  Left to the loop below, every h load sat
   // behind the previous h store (same array: the compiler keeps the order) -- 16 dependent round trips at 64 rows, 6.5 us of
   // o_proj's 24.6 (stamps, Qwen3-14B int4, B = 64).
@@ -740,24 +753,30 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           else h0 = (float)h[(size_t)m * p.ldo + n];
           const AT hv = (AT)(h0 + y);
           h[(size_t)m * p.ldo + n] = hv;
-          if constexpr (MT == 1) hsq[r] = (float)hv * (float)hv;
+          if constexpr (NH) hsq[mt * 4 + r] = (float)hv * (float)hv;
         }
       }
     }
-  if constexpr (MT == 1) {
+  if constexpr (NH) {
     if (want_sq) {
       // sum of h^2 per row over this group's 8 tiles x 16 columns, in a fixed order: [wave][row][column] through LDS,
-      // 256 threads add the 8 waves, a 16-lane butterfly adds the columns
+      // a thread per (row, column) adds the 8 waves, a 16-lane butterfly adds the columns
       float* sq = (float*)smem;                   // (the activation buffers are free: the slice loop ended on a barrier)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq[(wave * 16 + g * 4 + r) * 16 + c16] = hsq[r];
-      __syncthreads();
-      if (tid < 256) {
-        float v = 0.f;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int w = 0; w < SK_NW; ++w) v += sq[(w * 16 + (tid >> 4)) * 16 + (tid & 15)];
+        for (int r = 0; r < 4; ++r) sq[(wave * MB + mt * 16 + g * 4 + r) * 16 + c16] = hsq[mt * 4 + r];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < (MB * 16 + SK_NW * 64 - 1) / (SK_NW * 64); ++it) {
+        const int idx = tid + it * (SK_NW * 64);           // (MB * 16 is a multiple of 256: whole 16-lane groups are in or out)
+        float v = 0.f;
+        if (idx < MB * 16) {
+#pragma unroll
+          for (int w = 0; w < SK_NW; ++w) v += sq[(w * MB + (idx >> 4)) * 16 + (idx & 15)];
+        }
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        if ((tid & 15) == 0) p.sq_out[(size_t)grp * 16 + (tid >> 4)] = v;
+        if (idx < MB * 16 && (idx & 15) == 0) p.sq_out[(size_t)grp * p.sq_ld + row0 + (idx >> 4)] = v;
       }
     }
   }
@@ -981,7 +1000,7 @@ extern "C" int mi_debug_sk_trace_dump(const char* path) {
 
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr, int ksplit) {
   const bool defer_norm = c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && c.norm_w != nullptr;
-  if (c.pro != PRO_NONE && !defer_norm && !(rows <= 16 && c.sq_in != nullptr && c.sq_parts > 0))
+  if (c.pro != PRO_NONE && !defer_norm && !(gemm_skinny_handover_ld(W, c, rows) > 0 && c.sq_in != nullptr && c.sq_parts > 0))
     return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first (or hand over the row sums of squares)");
   if (c.sq_in != nullptr && c.sq_parts > SQ_PARTS_MAX) return fail(MI_ERR_INVALID, "gemm_skinny: norm hand-over from more than 64 tile groups");
   SkinnyPlan pl = skinny_plan(W, c, rows);
@@ -996,8 +1015,10 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   p.x = c.x; p.ldx = c.ldx; p.M = (int)rows;
   p.w = W.w; p.N = W.N; p.K = W.K;
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.epi == EPI_SWIGLU ? c.pair_offset : 0;
-  p.sq_out = (pl.mt == 1 && c.epi == EPI_RESID) ? c.sq_out : nullptr;
-  p.sq_in = (pl.mt == 1 && c.pro == PRO_NORM) ? c.sq_in : nullptr; p.sq_parts = c.sq_parts;
+  const bool nh = (pl.mt == 1 || pl.mt == 2) && c.act != MI_F32;
+  p.sq_out = (nh && c.epi == EPI_RESID) ? c.sq_out : nullptr;
+  p.sq_in = (nh && c.pro == PRO_NORM) ? c.sq_in : nullptr; p.sq_parts = c.sq_parts;
+  p.sq_ld = pl.nslab * 16 * pl.mt;
   p.norm_w = c.norm_w; p.eps = c.eps; p.rnd = c.rnd;
   p.ntiles = pl.ntiles; p.ksplit = pl.ksplit; p.nchunks = pl.nchunks;
   p.nslab = pl.nslab; p.nunits = pl.ngroups * pl.ksplit;
@@ -1038,5 +1059,17 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
 }
 
 int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ksplit; }
+
+// RMSNorm hand-over between two launches: row stride of the [tile groups][ld] table of sums of squares that this call would
+// write (residual epilogue) or read (PRO_NORM) -- its rows padded to whole workgroups -- or 0 when its instantiation
+// (more than 32 rows per workgroup, float32 activations) keeps the separate norm launch.  Producer and consumer of one
+// hand-over must agree on it.
+int gemm_skinny_handover_ld(const LinearW& W, const GemvCall& c, size_t rows) {
+  if (c.act == MI_F32) return 0;
+  const SkinnyPlan pl = skinny_plan(W, c, rows);
+  if (pl.mt != 1 && pl.mt != 2) return 0;
+  return pl.nslab * 16 * pl.mt;
+}
+int gemm_skinny_tile_groups(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ngroups; }
 
 }  // namespace mi

@@ -109,6 +109,8 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows);
 size_t gemm_skinny_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows);
 int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows);
 int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows);
+int gemm_skinny_handover_ld(const LinearW& W, const GemvCall& c, size_t rows);     // > 0: the call can leave / take the RMSNorm hand-over
+int gemm_skinny_tile_groups(const LinearW& W, const GemvCall& c, size_t rows);
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr,
                        int ksplit = 0);
 

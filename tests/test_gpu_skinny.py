@@ -234,7 +234,7 @@ def test_int8_decode_rows(act, kind, M, N, K, ksplit):
     _assert_close(host(out2), round_to(matmul_nt(x[:8], wdense), act), act)
 
 
-@pytest.mark.parametrize("B", [3, 12])
+@pytest.mark.parametrize("B", [3, 12, 24, 40, 64])      # 16-, 32-row workgroups; 48 rows keep the norm launch (dense) / slabs of 32 (int4); 64 rows
 @pytest.mark.parametrize("name", ["llama_q4_bf16", "llama_q8_f16", "llama_bf16_gqa", "qwen3_bf16"])
 def test_norm_handover_between_launches(tiny_dirs, name, B):
     """RMSNorm statistics handed from the residual epilogue of one launch to the staging of the next (no rmsnorm
