@@ -11,9 +11,12 @@ import pytest
 from mlx_parallm_amd.tiny_model import build_tiny_model
 from oracle import ref_generate
 
-GOLDEN = sorted(p for p in (Path(__file__).resolve().parent / "golden").glob("*.npz") if not p.stem.startswith("wide_"))
+GOLDEN = sorted(p for p in (Path(__file__).resolve().parent / "golden").glob("*.npz")
+                if not p.stem.startswith(("wide_", "serving_")))
 # production-width cases (make_golden_wide.py): minutes of oracle time each, so the CPU suite only checks the files
-WIDE = sorted((Path(__file__).resolve().parent / "golden").glob("wide_*.npz"))
+WIDE = sorted(p for p in (Path(__file__).resolve().parent / "golden").glob("wide_*.npz") if not p.stem.endswith("_logits"))
+SERVING = sorted((Path(__file__).resolve().parent / "golden").glob("serving_*.npz"))
+ENVELOPE = Path(__file__).resolve().parent / "golden" / "envelope"
 
 
 def test_golden_files_present():
@@ -54,3 +57,49 @@ def test_wide_golden_files_are_consistent(path):
     assert np.allclose(g["margins"], g["top_vals"][..., 0] - g["top_vals"][..., 1])
     if spec["temp"] == 0.0:
         assert np.array_equal(g["tokens"], g["top_ids"][..., 0])
+
+
+@pytest.mark.parametrize("path", SERVING, ids=[p.stem for p in SERVING])
+def test_serving_golden_files_are_consistent(path):
+    """tests/golden/serving_*.npz (make_golden_serving.py): the oracle's solo runs of the four sequences of the serving
+    schedule -- shapes follow the schedule in the spec, greedy tokens are the arg-max ids."""
+    g = np.load(path)
+    spec = json.loads(str(g["spec"]))
+    assert len(spec["prompt_lens"]) == 4 and sum(spec["chunks"]) == spec["prompt_lens"][3]
+    for i in range(4):
+        n = 1 + spec["steps"] if i < 3 else spec["steps"] - (spec["arrive_step"] + len(spec["chunks"])) + 1
+        assert g[f"seq{i}_tokens"].shape == (n,) and g[f"seq{i}_top_ids"].shape == (n, 8)
+        assert np.array_equal(g[f"seq{i}_tokens"], g[f"seq{i}_top_ids"][:, 0])
+        assert np.all(g[f"seq{i}_logprobs"] <= 0) and np.all(g[f"seq{i}_margins"] >= 0)
+    assert max(spec["prompt_lens"][:3]) + spec["steps"] > 1024          # the decode rows cross the 16-block boundary
+
+
+def test_every_wide_case_has_its_accumulation_envelope():
+    """tests/golden/envelope/<case>.npz (make_golden_wide.py --envelope): the oracle re-run with float32 accumulators in two
+    summation orders.  The GPU tests take their tolerances from these files, so each must be there, cover the case's
+    (step, row) grid and carry a summary that is what its arrays say."""
+    missing = [p.stem for p in WIDE if not (ENVELOPE / p.name).exists()]
+    assert not missing, f"run tests/golden/make_golden_wide.py --envelope {' '.join(missing)}"
+    for p in WIDE:
+        g, e = np.load(p), np.load(ENVELOPE / p.name)
+        summ = json.loads(str(e["summary"]))
+        for mode in ("f32_seq32", "f32_pairwise"):
+            lp = e[f"lp_{mode}"]
+            assert lp.shape == g["logprobs"].shape and e[f"top_lp_{mode}"].shape == g["top_vals"].shape
+            d = np.abs(lp.astype(np.float64) - g["logprobs"].astype(np.float64))
+            assert abs(float(d.max()) - summ[mode]["max_lp"]) <= 1e-6 and abs(float(d.mean()) - summ[mode]["mean_lp"]) <= 1e-6
+            assert summ[mode]["id_flips"] == int((e[f"argmax_{mode}"] != g["top_ids"][:, :, 0]).sum())
+        # the two orders are different arithmetic: they do not coincide, and neither is far from the exact oracle
+        assert summ["seq32_vs_pairwise"]["max_lp"] > 0
+        assert max(summ["f32_seq32"]["max_lp"], summ["f32_pairwise"]["max_lp"]) <= (0.1 if not json.loads(str(g["spec"]))["paged"] else 2e-2)
+
+
+def test_full_logits_of_the_sampled_case_are_the_oracles():
+    """wide_mistral_int4_topp_paged_logits.npz: full last-position logits of a few (step, row) pairs; their 8 largest values
+    must be the ones stored in the case file."""
+    f = Path(__file__).resolve().parent / "golden" / "wide_mistral_int4_topp_paged_logits.npz"
+    assert f.exists(), "run tests/golden/make_golden_wide.py --logits"
+    full, g = np.load(f), np.load(f.with_name("wide_mistral_int4_topp_paged.npz"))
+    for (s_, b), lg in zip(full["pairs"].tolist(), full["logits"]):
+        order = np.argsort(-lg, kind="stable")[:8]
+        assert np.array_equal(order, g["top_ids"][s_, b]) and np.allclose(lg[order], g["top_vals"][s_, b], atol=1e-6)

@@ -17,7 +17,8 @@ from mlx_parallm_amd.engine import SampleArgs  # noqa: E402
 from mlx_parallm_amd.tiny_model import build_tiny_model  # noqa: E402
 
 # (wide_*.npz: production-width cases with their own test, tests/test_gpu_golden_wide.py)
-GOLDEN = sorted(p for p in (Path(__file__).resolve().parent / "golden").glob("*.npz") if not p.stem.startswith("wide_"))
+GOLDEN = sorted(p for p in (Path(__file__).resolve().parent / "golden").glob("*.npz")
+                if not p.stem.startswith(("wide_", "serving_")))
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[p.stem for p in GOLDEN])
