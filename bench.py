@@ -192,6 +192,8 @@ OTHER_CONFIGS = [
     # round-2 profiles measured, so that is what runs here)
     dict(config="3: Mistral-7B int4-g64, batch 8, top-p 0.9 / T=1 sampling with logprobs", workload="mistral-7b-int4", batch=8,
          lora=0, kv_modes=("model", "float32"), mixed=False),
+    dict(config="3b (north_star: int4 / int8-quantised weights): Mistral-7B int8-g64, batch 8, top-p 0.9 / T=1 sampling with logprobs",
+         workload="mistral-7b-int8", batch=8, lora=0, kv_modes=("model",), mixed=False),
     dict(config="4: Qwen3-14B bf16, batch 32 (all of config 4's sequences on one GPU), greedy", workload="qwen3-14b-bf16",
          batch=32, lora=0, kv_modes=("model",), mixed=False),
     dict(config="5: Qwen3-14B int4-g64 + rank-16 LoRA on q/v of the last 8 layers, batch 64 (all of config 5's sequences on "
