@@ -55,9 +55,16 @@ def envelope_of(stem: str):
     f = GOLD / "envelope" / f"{stem}.npz"
     if not f.exists():
         return None
-    summ = json.loads(str(np.load(f)["summary"]))
+    e = np.load(f)
+    summ = json.loads(str(e["summary"]))
     a, b = summ["f32_seq32"], summ["f32_pairwise"]
-    return {k: max(a.get(k, 0.0), b.get(k, 0.0)) for k in ("max_lp", "mean_lp", "max_top8_lp", "id_flips")}
+    env = {k: max(a.get(k, 0.0), b.get(k, 0.0)) for k in ("max_lp", "mean_lp", "max_top8_lp", "id_flips")}
+    # the largest oracle margin at which a float32-accumulating variant's arg-max left the oracle's: a flip of the device's
+    # greedy id is the same phenomenon up to that margin (x ENVELOPE_FACTOR), and never less than 3 x the logprob noise
+    g = np.load(GOLD / f"{stem}.npz")
+    flipped = (e["argmax_f32_seq32"] != g["top_ids"][:, :, 0]) | (e["argmax_f32_pairwise"] != g["top_ids"][:, :, 0])
+    env["flip_margin"] = float(g["margins"][flipped].max()) if flipped.any() else 0.0
+    return env
 
 
 class _Checkpoints:
@@ -123,6 +130,9 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
     prompts = wide_models.prompts_for(spec, cfg["vocab_size"])
     kv = model.engine.new_kv(B, capacity=spec["L0"] + steps + 2, kv_dtype="float32" if exact else "model")
     margin_eps, lp_eps = (EXACT_MARGIN, EXACT_LP) if exact else (MODELKV_MARGIN, MODELKV_LP)
+    env = envelope_of(path.stem)
+    if env is not None:        # greedy flips only where the CPU's own float32-accumulating variants could flip (backstop: the old bound)
+        margin_eps = min(margin_eps, max(ENVELOPE_FACTOR * env["flip_margin"], 3.0 * ENVELOPE_FACTOR * env["max_lp"]))
     y = prompts
     near, lp_err, top_err, decided, lp_sum, lp_n = 0, 0.0, 0.0, 0, 0.0, 0
     drawn = []
@@ -157,7 +167,6 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
                         top_err = max(top_err, abs(dev[i] - (v - logz)))
         y = want[:, None]
     total = steps * B
-    env = envelope_of(path.stem)
     print(f"{path.stem}: mismatching ids {near}/{total} (oracle margins <= {margin_eps}: {int((g['margins'] <= margin_eps).sum())}), "
           f"|logprob - oracle| max {lp_err:.2e} mean {lp_sum / max(lp_n, 1):.2e}, max top-8 logprob error {top_err:.2e}; "
           f"CPU float32-accumulation envelope: {env}")
@@ -167,11 +176,15 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
     if env is not None:
         # the bound that does not come from the kernels under test
         f = ENVELOPE_FACTOR
-        assert lp_err <= f * env["max_lp"], (path.stem, "max |logprob - exact|", lp_err, env)
+        # (one bound for the chosen token and the 8 largest: in the 16-bit mode a logprob error IS a one-ulp flip of a logit --
+        # 0.031 below |logit| 8, 0.0625 above -- and which of a row's large logits flips is chance)
+        assert lp_err <= f * max(env["max_lp"], env["max_top8_lp"]), (path.stem, "max |logprob - exact|", lp_err, env)
         assert lp_sum / max(lp_n, 1) <= f * env["mean_lp"], (path.stem, "mean |logprob - exact|", lp_sum / max(lp_n, 1), env)
         if greedy:
             assert top_err <= f * max(env["max_top8_lp"], env["max_lp"]), (path.stem, "top-8 logprobs", top_err, env)
-            assert near <= int(np.ceil(f * env["id_flips"])) + (0 if exact else 1), (path.stem, "greedy id flips", near, env)
+            # (every flip was checked against the envelope's flip margin where it happened; the count is bounded by how many
+            # (step, row) pairs lie under that margin at all)
+            assert near <= int((g["margins"] <= margin_eps).sum()), (path.stem, "greedy id flips", near, env)
     if exact and greedy:
         assert near <= 2, (path.stem, near, total)
     elif greedy:
