@@ -46,6 +46,7 @@ struct FusedLinear {
   int dense_dtype = -1, scale_dtype = -1;
   size_t w_bytes = 0, s_bytes = 0;
   void* w = nullptr; void* scales = nullptr; void* biases = nullptr;
+  void* w_hilo = nullptr;        // f16 dense weights in the float32-activation (PagedKVCache) mode: [hi | lo] bf16 copy, made on first use
   float* lora_a[2] = {nullptr, nullptr};
   float* lora_b[2] = {nullptr, nullptr};
   int seen_w[3] = {0, 0, 0}, seen_s[3] = {0, 0, 0}, seen_b[3] = {0, 0, 0};
@@ -115,6 +116,7 @@ struct mi_engine {
   int opt_short_prefill_skinny = 1;   // short prefill / mixed calls on the weight-streaming kernel instead of the tile GEMM (gemv_rows)
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
   bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0, sq_ld = 0;
+  bool opt_f16_hilo = true;              // f16 dense weights in the float32-activation mode through an exact [hi | lo] bf16 copy (matrix cores)
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
                                          // Off: measured on Mistral-7B bf16 B=8 the in-launch seam costs what the kernel
                                          // boundary it replaces costs (bit 0: +-0 %, bit 1: -2 %), DESIGN.md section 5
@@ -263,7 +265,7 @@ int make_f32_copy(mi_engine* e, const void* src, int n, void** dst) {
 }
 
 void free_linear(FusedLinear& f) {
-  hipFree(f.w); hipFree(f.scales); hipFree(f.biases);
+  hipFree(f.w); hipFree(f.scales); hipFree(f.biases); hipFree(f.w_hilo);
   for (int i = 0; i < 2; ++i) { hipFree(f.lora_a[i]); hipFree(f.lora_b[i]); }
 }
 
@@ -323,11 +325,35 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
 }
 
 // y = W x for `rows` rows, split into launches of at most 16 (MFMA) / 8 (generic) rows
-int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_t es_in, size_t es_out,
+int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, GemvCall c, size_t rows, size_t es_in, size_t es_out,
+                 const char* prof, bool sq_was_valid);
+int gemv_rows(mi_engine* e, const FusedLinear& f0, GemvCall c, size_t rows, size_t es_in, size_t es_out,
               const char* prof) {
   c.force_v1 = e->opt_force_v1;
   const bool sq_was_valid = e->sq_valid;      // whatever runs now consumes or invalidates the hand-over
   e->sq_valid = false;
+  // An f16 model in the PagedKVCache mode (float32 activations): the matrix-core kernels of that mode multiply an exact
+  // three-way bf16 split of x by bf16 weights, so an f16 matrix is used through its exact [hi | lo] bf16 copy (2 K
+  // columns, x walked twice: GemvCall::kx) -- made here on first use, twice the matrix's bytes.  Everything that is
+  // about x (norms, LoRA down-projection, the split) keeps the true K of f0.
+  if (c.act == MI_F32 && f0.W.wk == WK_F16 && f0.W.layout == 1 && e->opt_f16_hilo && !e->opt_force_v1 && f0.W.K % 256 == 0) {
+    FusedLinear& fm = const_cast<FusedLinear&>(f0);
+    if (fm.w_hilo == nullptr) {
+      MI_HIP(hipMalloc(&fm.w_hilo, 2 * (size_t)f0.W.N * f0.W.K * sizeof(uint16_t)));
+      MI_TRY(launch_f16_to_hilo(f0.W, fm.w_hilo, e->stream));
+    }
+    FusedLinear fh = f0;                       // (a view: the pointers stay owned by f0)
+    fh.W.wk = WK_BF16; fh.W.w = fm.w_hilo; fh.W.K = 2 * f0.W.K;
+    c.kx = f0.W.K;
+    return gemv_rows_on(e, fh, f0, c, rows, es_in, es_out, prof, sq_was_valid);
+  }
+  return gemv_rows_on(e, f0, f0, c, rows, es_in, es_out, prof, sq_was_valid);
+}
+
+// f: the matrix the matmul kernels stream (f0 itself, or its [hi | lo] view); f0: the linear as loaded (true K, LoRA)
+int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, GemvCall c, size_t rows, size_t es_in, size_t es_out,
+                 const char* prof, bool sq_was_valid) {
+  const int KT = f0.W.K;                      // the true K: columns of x
   // Which kernel for a call that is not a pure decode step (prefill, mixed step)?  Measured on Mistral-7B shapes, one prompt
   // of L tokens (tools/debug/prefill_sweep.py, ms for the whole call): dense 16-bit weights -- streaming kernel 4.2 / 5.1 /
   // 6.1 / 6.9 at L = 32 / 64 / 96 / 128 against 5.2 / 5.5 / 5.6 / 5.8 on the K-split 128 x 128 tile: the hand-over is at ~80 rows;
@@ -344,8 +370,8 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     if (gemm_skinny_supported(f.W, probe, half) && f.W.lora_b[0] == nullptr && f.W.lora_b[1] == nullptr) {
       Prof pr(e, prof);
       if (c.pro == PRO_NORM) {
-        MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
-        c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+        MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, KT, (int)rows, KT, c.eps, c.act, e->stream, true, c.rnd));
+        c.x = e->xn; c.ldx = KT; c.pro = PRO_NONE;
       }
       const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
       for (size_t r = 0; r < rows; r += half) {
@@ -392,19 +418,19 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     c.M = (int)rows;
     const int take_ld = (c.act != MI_F32 && c.pro == PRO_NORM) ? gemm_skinny_handover_ld(f.W, c, rows) : 0;
     const bool handed = sq_was_valid && e->opt_norm_handover && take_ld > 0 && take_ld == e->sq_ld &&
-                        e->sq_src == c.x && e->sq_K == f.W.K && c.ldx == f.W.K;
+                        e->sq_src == c.x && e->sq_K == KT && c.ldx == KT;
     c.M = (int)rows;
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {     // (normalises on its own when c.pro says so)
       c.lora_t = e->lora_t; c.lora_t_ld = 128;
-      MI_TRY(launch_lora_down(f.W, c, e->lora_t, 128, e->stream));
+      MI_TRY(launch_lora_down(f0.W, c, e->lora_t, 128, e->stream));
     }
     // float32 activations without logical rounding (PagedKVCache mode after layer 0): the kernel applies the row scale
     // of the RMSNorm in its epilogue (gemm_skinny.hip "defer_norm") -- no norm launch, nothing waits for row statistics
     const bool defer = e->opt_defer_norm && c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && !handed;
     if (handed) { c.sq_in = e->d_sq; c.sq_parts = e->sq_parts; }
     else if (c.pro == PRO_NORM && !defer) {
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
-      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, KT, (int)rows, KT, c.eps, c.act, e->stream, true, c.rnd));
+      c.x = e->xn; c.ldx = KT; c.pro = PRO_NONE;
     }
     const size_t need = gemm_skinny_ws_bytes(f.W, c, rows);
     const int groups = gemm_skinny_groups(f.W, c, rows);
@@ -439,22 +465,22 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     Prof pr(e, prof);
     const GemvCall c_in = c;                 // (the LoRA down-projection reads the caller's x and normalises on its own)
     if (c.act == MI_F32) {      // PagedKVCache mode: (norm +) exact three-way split of x, then the same tile GEMM over 3 K
-      const size_t need = split3_bytes(rows, f.W.K);
+      const size_t need = split3_bytes(rows, KT);
       if (need > e->xs_cap) {
         MI_HIP(hipStreamSynchronize(e->stream));
         hipFree(e->xs); e->xs = nullptr; e->xs_cap = 0;
         MI_HIP(hipMalloc(&e->xs, need));
         e->xs_cap = need;
       }
-      MI_TRY(launch_split3_rows(c.x, c.ldx, c.pro == PRO_NORM ? c.norm_w : nullptr, c.eps, e->xs, (int)rows, f.W.K, e->stream));
-      c.x = e->xs; c.ldx = 3 * f.W.K; c.pro = PRO_NONE;
+      MI_TRY(launch_split3_rows(c.x, c.ldx, c.pro == PRO_NORM ? c.norm_w : nullptr, c.eps, e->xs, (int)rows, KT, e->stream));
+      c.x = e->xs; c.ldx = 3 * KT; c.pro = PRO_NONE;
     } else if (c.pro == PRO_NORM) {    // (one workgroup per row also here: one L2 round trip per row instead of a wave's 16)
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true));
-      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, KT, (int)rows, KT, c.eps, c.act, e->stream, true));
+      c.x = e->xn; c.ldx = KT; c.pro = PRO_NONE;
     }
     void* scratch = nullptr;
     if (wk_is_quant(f.W.wk)) {               // int4: the GEMM multiplies by a [hi | lo] 16-bit copy made on the fly
-      const size_t need = dequant_hilo_bytes(f.W.N, f.W.K);
+      const size_t need = dequant_hilo_bytes(f.W.N, KT);
       if (need > e->deq_cap) {
         MI_HIP(hipStreamSynchronize(e->stream));
         hipFree(e->deq_scratch);
@@ -472,8 +498,8 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {   // y = T(y + T(scale (x A) B)) on the adapted columns
       GemvCall cl = c.act == MI_F32 ? c_in : c;
       cl.M = (int)rows;
-      MI_TRY(launch_lora_down(f.W, cl, e->lora_t, 128, e->stream));
-      MI_TRY(launch_lora_up_add(f.W, cl, e->lora_t, 128, e->stream));
+      MI_TRY(launch_lora_down(f0.W, cl, e->lora_t, 128, e->stream));
+      MI_TRY(launch_lora_up_add(f0.W, cl, e->lora_t, 128, e->stream));
     }
     return MI_OK;
   }
@@ -483,10 +509,10 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     // over W.  A tile GEMM with the three-way split of x is the next step for this mode.
     Prof pr(e, prof);
     const bool lora32 = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
-    if (lora32) { GemvCall cl = c; cl.M = (int)rows; MI_TRY(launch_lora_down(f.W, cl, e->lora_t, 128, e->stream)); }
+    if (lora32) { GemvCall cl = c; cl.M = (int)rows; MI_TRY(launch_lora_down(f0.W, cl, e->lora_t, 128, e->stream)); }
     if (c.pro == PRO_NORM) {
-      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, f.W.K, (int)rows, f.W.K, c.eps, c.act, e->stream, true, c.rnd));
-      c.x = e->xn; c.ldx = f.W.K; c.pro = PRO_NONE;
+      MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, KT, (int)rows, KT, c.eps, c.act, e->stream, true, c.rnd));
+      c.x = e->xn; c.ldx = KT; c.pro = PRO_NONE;
     }
     // workspace for every chunk size that is launched below: full 32-row chunks and the tail, whose plan (tile rows,
     // K split) is made for ITS row count and can need more partial-tile space than the 32-row plan
@@ -526,9 +552,11 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     }
     return MI_OK;
   }
-  const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
+  // the generic per-8 / per-16-row kernels read the matrix as loaded (an f16 model falls back to its f16 weights, exact VALU)
+  c.kx = 0;
+  const bool has_lora = f0.W.lora_b[0] != nullptr || f0.W.lora_b[1] != nullptr;
   GemvCall probe = c; probe.M = (int)std::min<size_t>(rows, 16);
-  const bool mfma = gemv_mfma_supported(f.W, probe);
+  const bool mfma = gemv_mfma_supported(f0.W, probe);
   const size_t step = mfma ? 16 : 8;
   // measurement: the MFMA kernel is stamped with its own dispatch begin/end (hipExtLaunchKernelGGL);
   // other paths are bracketed with events on the stream
@@ -550,9 +578,9 @@ int gemv_rows(mi_engine* e, const FusedLinear& f, GemvCall c, size_t rows, size_
     if (r0) cc.resid = r0 + r * (size_t)c.ldo * es_in;
     if (has_lora) {
       cc.lora_t = e->lora_t + r * 128; cc.lora_t_ld = 128;
-      MI_TRY(launch_lora_down(f.W, cc, e->lora_t + r * 128, 128, e->stream));
+      MI_TRY(launch_lora_down(f0.W, cc, e->lora_t + r * 128, 128, e->stream));
     }
-    MI_TRY(launch_gemv(f.W, cc, e->stream));
+    MI_TRY(launch_gemv(f0.W, cc, e->stream));
   }
   return MI_OK;
 }
@@ -1671,6 +1699,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "short_prefill_skinny") { e->opt_short_prefill_skinny = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
+  if (k == "f16_hilo") { e->opt_f16_hilo = value != 0; return MI_OK; }
   if (k == "seam_spin_limit") {
     if (value < 0 || value > (int64_t)0x7fffffff) return fail(MI_ERR_INVALID, "seam_spin_limit out of range");
     e->seam_spin_limit = (unsigned)value; return MI_OK;

@@ -856,8 +856,14 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
   }
   const bool x32 = c.act == MI_F32;        // c.x is the [hi | mid | lo] bf16 image of launch_split3_rows, c.ldx = 3 K
   if (x32) {
-    if (c.ldx != 3 * W.K) return fail(MI_ERR_INVALID, "gemm_prefill: float32 activations must be split first (launch_split3_rows)");
-    p.ka = 3 * W.K; p.K = (wk_is_quant(W.wk) ? 6 : 3) * W.K; p.out32 = 1;
+    // c.kx > 0: W is the persistent [hi | lo] bf16 copy of an f16 matrix (2 kx columns, launch_f16_to_hilo) -- the same
+    // walk as over an int4 matrix's on-the-fly [hi | lo] copy: x = [hi | mid | lo] (3 kx) against W (2 kx) over 6 kx steps
+    const bool hilo = c.kx > 0 && !wk_is_quant(W.wk);
+    const int kt = hilo ? c.kx : W.K;      // the true K
+    if (hilo && (W.K != 2 * c.kx || W.wk != WK_BF16)) return fail(MI_ERR_INVALID, "gemm_prefill: a [hi | lo] matrix has 2 kx bf16 columns");
+    if (c.ldx != 3 * kt) return fail(MI_ERR_INVALID, "gemm_prefill: float32 activations must be split first (launch_split3_rows)");
+    p.ka = 3 * kt; p.K = ((wk_is_quant(W.wk) || hilo) ? 6 : 3) * kt; p.out32 = 1;
+    if (hilo) p.kw = 2 * kt;
   }
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;
   const bool sw = c.epi == EPI_SWIGLU;

@@ -76,6 +76,7 @@ struct SkinnyParams {
   // w * (x * rs) by one rounding per element (~6e-8 relative); rounded (layer-0) calls keep the separate norm launch.
   int defer_norm;
   float* sqws;                     // [tile groups][ksplit][16 MT] row sums of squares of the K slices (ksplit > 1)
+  int kx;            // columns of x (= K, or K / 2 when W is an f16 model's [hi | lo] copy: x is walked twice, k mod kx)
   int ntiles;        // 16-row tiles (tile pairs for SwiGLU)
   int ksplit;        // workgroups per tile group along K
   // Row slabs (int4 above 32 rows): the rows are cut into `nslab` slabs of 16 MT rows and every (tile group, K slice) unit is
@@ -223,17 +224,19 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   auto load_x = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int k = c * SK_KC + xk[i];
-      xr[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0));
+      const int k0 = c * SK_KC + xk[i];
+      const int k1 = k0 < p.K ? k0 : 0;
+      const int k = k1 >= p.kx ? k1 - p.kx : k1;            // ([hi | lo] weights: the second half of K meets the same x again)
+      xr[i] = *(const u32x4*)(xrow[i] + k);
       if constexpr (X32) {
-        xr2[i] = *(const u32x4*)(xrow[i] + (k < p.K ? k : 0) + 4);
+        xr2[i] = *(const u32x4*)(xrow[i] + k + 4);
         if (dn) {
-          xnw[i] = *(const u32x4*)((const float*)p.norm_w + (k < p.K ? k : 0));
-          xnw2[i] = *(const u32x4*)((const float*)p.norm_w + (k < p.K ? k : 0) + 4);
+          xnw[i] = *(const u32x4*)((const float*)p.norm_w + k);
+          xnw2[i] = *(const u32x4*)((const float*)p.norm_w + k + 4);
         }
       }
       if constexpr (NH) {
-        if (norm) xw[i] = *(const u32x4*)((const AT*)p.norm_w + (k < p.K ? k : 0));
+        if (norm) xw[i] = *(const u32x4*)((const AT*)p.norm_w + k);
       }
     }
   };
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
           float ss = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { ss = fmaf(xf[j], xf[j], ss); xf[j] *= wf[j]; }
-          if (fresh) sqacc[i] += ss;
+          if (fresh && c * SK_KC < p.kx) sqacc[i] += ss;      // (each x once: not in the second pass of a [hi | lo] matrix)
         }
         AT hi[8], mid[8], lo[8];
 #pragma unroll
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
       if (p.ksplit > 1) {
         if (tid < MB) __hip_atomic_store(&p.sqws[((size_t)grp * p.ksplit + s) * MB + tid], slice_sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        if (tid < MB) rs_row[tid] = 1.0f / sqrtf(slice_sq / (float)p.K + p.eps);
+        if (tid < MB) rs_row[tid] = 1.0f / sqrtf(slice_sq / (float)p.kx + p.eps);
         __syncthreads();
       }
     }
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         if (tid < MB) {
           float tot = 0.f;
           for (int s2 = 0; s2 < p.ksplit; ++s2) tot += sqs[s2 * MB + tid];
-          rs_row[tid] = 1.0f / sqrtf(tot / (float)p.K + p.eps);
+          rs_row[tid] = 1.0f / sqrtf(tot / (float)p.kx + p.eps);
         }
         __syncthreads();
       }
@@ -1016,6 +1019,8 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   SkinnyParams p{};
   p.x = c.x; p.ldx = c.ldx; p.M = (int)rows;
   p.w = W.w; p.N = W.N; p.K = W.K;
+  p.kx = (c.kx > 0 && c.act == MI_F32) ? c.kx : W.K;
+  if (p.kx != W.K && (2 * p.kx != W.K || p.kx % SK_KC != 0)) return fail(MI_ERR_INVALID, "gemm_skinny: a [hi | lo] matrix has 2 kx columns, kx a multiple of 256");
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.epi == EPI_SWIGLU ? c.pair_offset : 0;
   const bool nh = (pl.mt == 1 || pl.mt == 2) && c.act != MI_F32;
   p.sq_out = (nh && c.epi == EPI_RESID) ? c.sq_out : nullptr;

@@ -46,6 +46,8 @@ struct GemvCall {
   const float* lora_t = nullptr;  // [M][2][max_rank] = round(x A) for the (up to 2) adapted row ranges
   int lora_t_ld = 0;
   int force_v1 = 0;
+  int kx = 0;                     // > 0: W is a [hi | lo] matrix of 2 kx columns (an f16 model in the float32-activation mode): the
+                                  // activations have kx columns and are walked twice (k mod kx); 0: W.K columns
   // RMSNorm hand-over between two launches of gemm_skinny.hip's 16-row instantiation: a residual epilogue leaves
   // sum(h^2) per (tile group, row) in sq_out; the next linear (pro = PRO_NORM) reads them as sq_in[sq_parts][16]
   float* sq_out = nullptr;
@@ -118,6 +120,8 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
 bool tiled_supported(int wk, int N, int K, int group);
 size_t tiled_bytes(int wk, int N, int K);
 int launch_repack_tiled(const LinearW& src_row_major, void* dst, hipStream_t st);
+// tile-major f16 (N x K) -> tile-major bf16 [hi | lo] (N x 2K), hi + lo == w exactly (repack.hip); dst: 2 x the source's bytes
+int launch_f16_to_hilo(const LinearW& tiled_f16, void* dst, hipStream_t st);
 
 // byte offset of the 16-byte piece holding W[row][k .. k+8) (k % 8 == 0) of a tile-major dense matrix
 __host__ __device__ inline size_t tiled_piece_dense16(size_t row, int k, int K) {

@@ -181,4 +181,37 @@ int launch_repack_tiled(const LinearW& src, void* dst, hipStream_t st) {
   return MI_OK;
 }
 
+// Tile-major f16 matrix (N x K) -> tile-major bf16 matrix (N x 2K) whose columns [0, K) hold hi = bf16(w) and [K, 2K) hold
+// lo = bf16(w - hi).  An f16 value has 11 significant bits and the bf16 range covers f16's, so hi + lo == w EXACTLY: the
+// float32-activation kernels (x split exactly into three bf16 terms) then compute x . w as a float32 dot product of exact
+// products for an f16 model too (PagedKVCache mode of the reference: base.py:111-112 promotes everything behind layer 0 to
+// float32 whatever the model dtype).  The conversion keeps a block's lane order: block (tile t, k block j) of w becomes
+// blocks (t, j) and (t, K / 32 + j) of the result.
+__global__ void f16_to_hilo_kernel(const uint16_t* src, uint16_t* dst, int N, int K) {
+  const size_t pieces = (size_t)N * (K / 8);
+  const size_t kb = (size_t)(K / 32);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pieces; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = idx >> 6, lane = idx & 63;
+    const size_t t = blk / kb, j = blk % kb;
+    const u32x4 v = *(const u32x4*)(src + idx * 8);
+    const _Float16* h = (const _Float16*)&v;
+    __bf16 hi[8], lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float w = (float)h[i];
+      hi[i] = (__bf16)w;
+      lo[i] = (__bf16)(w - (float)hi[i]);
+    }
+    *(u32x4*)(dst + ((t * 2 * kb + j) * 64 + lane) * 8) = *(const u32x4*)hi;
+    *(u32x4*)(dst + ((t * 2 * kb + kb + j) * 64 + lane) * 8) = *(const u32x4*)lo;
+  }
+}
+
+int launch_f16_to_hilo(const LinearW& tiled_f16, void* dst, hipStream_t st) {
+  if (tiled_f16.wk != WK_F16 || tiled_f16.layout != 1) return fail(MI_ERR_INVALID, "f16_to_hilo: a tile-major f16 matrix is expected");
+  hipLaunchKernelGGL(f16_to_hilo_kernel, dim3(2048), dim3(256), 0, st, (const uint16_t*)tiled_f16.w, (uint16_t*)dst, tiled_f16.N, tiled_f16.K);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 }  // namespace mi

@@ -62,4 +62,7 @@ def tiny_dirs(tmp_path_factory):
          tie_word_embeddings=False, norm_jitter=0.1)
     make("llama_q8_f16", seed=5, vocab_size=512, dtype="float16", quantize_model=True, q_bits=8, hidden_size=128,
          layers=2, heads=4, kv_heads=4, intermediate_size=256, tie_word_embeddings=True)
+    # a dense f16 model wide enough (K % 256 == 0) for the [hi | lo] matrix-core path of the float32-activation mode
+    make("llama_f16", seed=6, vocab_size=512, dtype="float16", quantize_model=False, hidden_size=256, layers=2, heads=4,
+         kv_heads=2, intermediate_size=512, head_dim=64, tie_word_embeddings=False, norm_jitter=0.1)
     return out

@@ -53,7 +53,7 @@ def _logit_tol(cfg_name):
 
 @pytest.mark.parametrize("mode", ["model", "float32"])
 @pytest.mark.parametrize("name", ["llama_q4_f32", "llama_f32", "llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16",
-                                  "llama_q8_f16"])
+                                  "llama_q8_f16", "llama_f16"])
 def test_prefill_and_decode_logits(tiny_dirs, name, mode):
     """model(y, cache) logits: prefill (all positions) then 3 decode steps, ragged left padding."""
     model, ref, cfg = _load_pair(tiny_dirs, name)
@@ -77,7 +77,7 @@ def test_prefill_and_decode_logits(tiny_dirs, name, mode):
     model.engine.close()
 
 
-@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16", "llama_f16"])
 @pytest.mark.parametrize("B,L0", [(4, 40), (5, 64)])
 def test_float32_kv_prefill_through_the_tile_gemm(tiny_dirs, name, B, L0):
     """PagedKVCache mode, prompts of >= 32 rows in all: float32 activations are split exactly three ways
@@ -99,6 +99,33 @@ def test_float32_kv_prefill_through_the_tile_gemm(tiny_dirs, name, B, L0):
         assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
         nxt = np.argmax(want, axis=-1)[:, None]
     model.engine.close()
+
+
+def test_f16_model_in_float32_kv_mode_runs_on_the_matrix_cores_and_equals_the_exact_kernels(tiny_dirs):
+    """PagedKVCache mode of an f16 model (base.py:111-112 promotes to float32 whatever the model dtype): the linears go
+    through an EXACT [hi | lo] bf16 copy of the f16 weights on the float32-activation matrix-core kernels (x split three
+    ways) instead of the generic VALU kernel; both are float32 dot products of the same exact products, so the logits of
+    the two routes agree to float32 summation noise -- prefill (tile GEMM: 5 x 64 rows; streaming kernel: 2 x 9) and decode."""
+    model, ref, cfg = _load_pair(tiny_dirs, "llama_f16")
+    eng = model.engine
+    for B, L0 in ((5, 64), (2, 9)):
+        toks = _left_pad_prompts(cfg, B, L0)
+        outs = {}
+        for on in (1, 0):
+            eng.set_option("f16_hilo", on)
+            kv = eng.new_kv(B, capacity=L0 + 8, kv_dtype="float32")
+            lg = [eng.forward(toks, kv, all_positions=True)[:, -1]]
+            nxt = np.argmax(lg[0], axis=-1)[:, None].astype(np.int32)
+            for _ in range(3):
+                lg.append(eng.forward(nxt, kv))
+                nxt = np.argmax(lg[-1], axis=-1)[:, None].astype(np.int32)
+            outs[on] = np.stack(lg)
+            kv.close()
+        eng.set_option("f16_hilo", 1)
+        assert np.abs(outs[1] - outs[0]).max() <= 4e-3 and np.sqrt(((outs[1] - outs[0]) ** 2).mean()) <= 3e-4, \
+            (B, L0, np.abs(outs[1] - outs[0]).max())
+        assert not np.array_equal(outs[1], outs[0])       # (another summation order: the option really switches kernels)
+    eng.close()
 
 
 def _teacher_forced_greedy(model, ref, cfg, kvd, paged, B, L0, steps, margin_eps):
@@ -137,7 +164,7 @@ def test_greedy_bit_exact_float32_models(tiny_dirs, name, mode):
     model.engine.close()
 
 
-@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16", "llama_q8_f16"])
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16", "llama_q8_f16", "llama_f16"])
 def test_greedy_float32_kv_mode_16bit_models(tiny_dirs, name):
     """The reference's actual numerics (PagedKVCache float32 quirk): bit-exact ids, logprobs 1e-3."""
     model, ref, cfg = _load_pair(tiny_dirs, name)
@@ -147,7 +174,7 @@ def test_greedy_float32_kv_mode_16bit_models(tiny_dirs, name):
     model.engine.close()
 
 
-@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16", "llama_q8_f16"])
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16", "llama_q8_f16", "llama_f16"])
 def test_greedy_model_dtype_kv_16bit_models(tiny_dirs, name):
     """KV and activations in the 16-bit model dtype (the bandwidth-optimal default).  Logits are
     rounded to 16 bits, so exact ties are common; ids must match wherever the oracle's margin
