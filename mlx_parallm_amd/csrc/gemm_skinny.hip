@@ -211,7 +211,8 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   // +1.8 % (Qwen3-14B) / +3.2 % (Mistral-7B), int4 +-0; the 64-row form was built too and LOST 3 % (bf16) / 6.5 % (int4 + LoRA):
   // eight table loads per thread at the head and the normalisation of four pieces per chunk inside a loop that is already
   // bound by its vector instructions -- above 32 rows the separate norm launch stays.
-  constexpr bool NH = !X32 && (MT == 1 || MT == 2);
+  // (32 rows: 16-bit weights only -- int4 measured +-0, and the int8 SwiGLU form would spill inside its 128-register budget)
+  constexpr bool NH = !X32 && (MT == 1 || (MT == 2 && QB == 0));
   constexpr int MBC = MB < 64 ? MB : 64;
   __shared__ float rs_sh[NH ? MB : 16];
   __shared__ float sqp_sh[SK_NW * (NH ? MBC : 16)];
@@ -224,9 +225,11 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
   auto load_x = [&](int c) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int k0 = c * SK_KC + xk[i];
-      const int k1 = k0 < p.K ? k0 : 0;
-      const int k = k1 >= p.kx ? k1 - p.kx : k1;            // ([hi | lo] weights: the second half of K meets the same x again)
+      // ([hi | lo] weights, float32 activations only: the second half of K meets the same x again.  kx is a multiple of the
+      // chunk, so the wrap is uniform -- scalar arithmetic, no register per thread)
+      const int cb = c * SK_KC;
+      const int cw = (X32 && cb >= p.kx) ? cb - p.kx : cb;
+      const int k = cb + xk[i] < p.K ? cw + xk[i] : 0;
       xr[i] = *(const u32x4*)(xrow[i] + k);
       if constexpr (X32) {
         xr2[i] = *(const u32x4*)(xrow[i] + k + 4);
@@ -1022,7 +1025,7 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   p.kx = (c.kx > 0 && c.act == MI_F32) ? c.kx : W.K;
   if (p.kx != W.K && (2 * p.kx != W.K || p.kx % SK_KC != 0)) return fail(MI_ERR_INVALID, "gemm_skinny: a [hi | lo] matrix has 2 kx columns, kx a multiple of 256");
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.epi == EPI_SWIGLU ? c.pair_offset : 0;
-  const bool nh = (pl.mt == 1 || pl.mt == 2) && c.act != MI_F32;
+  const bool nh = (pl.mt == 1 || (pl.mt == 2 && !wk_is_quant(W.wk))) && c.act != MI_F32;
   p.sq_out = (nh && c.epi == EPI_RESID) ? c.sq_out : nullptr;
   p.sq_in = (nh && c.pro == PRO_NORM) ? c.sq_in : nullptr; p.sq_parts = c.sq_parts;
   p.sq_ld = pl.nslab * 16 * pl.mt;
@@ -1074,7 +1077,7 @@ int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) { retur
 int gemm_skinny_handover_ld(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.act == MI_F32) return 0;
   const SkinnyPlan pl = skinny_plan(W, c, rows);
-  if (pl.mt != 1 && pl.mt != 2) return 0;
+  if (pl.mt != 1 && !(pl.mt == 2 && !wk_is_quant(W.wk))) return 0;
   return pl.nslab * 16 * pl.mt;
 }
 int gemm_skinny_tile_groups(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ngroups; }
