@@ -105,12 +105,19 @@ int launch_j(const MfmaParams& p, hipStream_t st) {
 
 template <typename AT, bool Q4, int MB, bool SWIGLU, int NW>
 int launch_one(const MfmaParams& p, hipStream_t st) {
+  // make_params(): the chunk is the whole K up to 6144 (<= 8 rows) / 4096 (9..16 rows), else 4096 -- so only the
+  // single-buffered 8-row form ever holds more than 8 * NW * 64 columns (J = 2).  The other J = 2 forms are not
+  // instantiated: they would spill (tools/kernel_resources.py) and nothing selects them.
   if constexpr (MB == 8) {
-    if (phase_nbuf(p.K, p.kc, MB, Q4) == 2)      // K spans several activation chunks: the double-buffered instantiation
-      return p.kc <= 8 * NW * 64 ? launch_j<AT, Q4, MB, SWIGLU, NW, 1, true>(p, st) : launch_j<AT, Q4, MB, SWIGLU, NW, 2, true>(p, st);
+    if (phase_nbuf(p.K, p.kc, MB, Q4) == 2) {    // K spans several activation chunks: the double-buffered instantiation
+      if (p.kc > 8 * NW * 64) return fail(MI_ERR_INVALID, "gemv_mfma: a double-buffered chunk holds at most 4096 columns");
+      return launch_j<AT, Q4, MB, SWIGLU, NW, 1, true>(p, st);
+    }
+    if (p.kc > 8 * NW * 64) return launch_j<AT, Q4, MB, SWIGLU, NW, 2, false>(p, st);
+  } else {
+    if (p.kc > 8 * NW * 64) return fail(MI_ERR_INVALID, "gemv_mfma: 9..16 rows hold at most 4096 columns per chunk");
   }
-  if (p.kc <= 8 * NW * 64) return launch_j<AT, Q4, MB, SWIGLU, NW, 1, false>(p, st);
-  return launch_j<AT, Q4, MB, SWIGLU, NW, 2, false>(p, st);
+  return launch_j<AT, Q4, MB, SWIGLU, NW, 1, false>(p, st);
 }
 
 template <typename AT>

@@ -98,3 +98,21 @@ def test_integration_stub_is_the_generated_one():
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     assert gen.block() in (ROOT / "INTEGRATION.md").read_text(), "run tools/gen_integration_stub.py --write"
+
+
+def test_no_launched_kernel_spills_registers():
+    """The build keeps the compiler's resource report per source (csrc/*.res, Makefile); a kernel the engine launches
+    must not spill to scratch -- in a weight-streaming loop a spill costs more than any register it frees."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("kernel_resources", ROOT / "tools" / "kernel_resources.py")
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.collect()
+    if not rows:
+        pytest.skip("library built without the resource report (no csrc/*.res)")
+    names = {r["kernel"] for r in rows}
+    assert any(n.startswith("skinny_kernel<bf16, 0, 1, false, false>") for n in names), "demangling failed"
+    assert len(rows) > 500
+    bad = kr.spilling(rows)
+    assert not bad, "register spills in: " + ", ".join(f'{r["kernel"]} ({r["scratch"]} B/lane)' for r in bad)
