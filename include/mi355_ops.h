@@ -88,6 +88,10 @@ int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters,
  * cost model (returned in *ksplit_used); iters >= 1 also times that many back-to-back launches into *avg_ms. */
 int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters,
                       float* avg_ms);
+/* gemm_prefill.hip on its own: the tile GEMM of the prefill call (generate_step's first model call, utils.py:243-262: every
+ * nn.Linear over B x L rows at once).  a->M rows of 16-bit activations, tile-major dense 16-bit weights, a->pro =
+ * MI_PRO_NONE; plain / residual / SwiGLU epilogues.  iters >= 1 also times that many back-to-back launches into *avg_ms. */
+int mi_op_gemm_prefill(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
 /* chain.hip on its own: up to 4 dependent linears (a[i].x may be what a[i-1] wrote: wait_prev[i] != 0) of a decode step of
  * a[0].M <= 8 rows as ONE persistent launch; tile-major dense 16-bit weights.  Replaces the o_proj / gate|up / down_proj /
  * next q|k|v launches of a decoder block (llama.py:143,165,188-190,64-67).  iters >= 1 also times that many back-to-back

@@ -110,6 +110,7 @@ SIGNATURES = {
     "mi_op_gemv_bench": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_float)]),
     "mi_op_gemm_skinny": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_int), C.c_int,
                                     C.POINTER(C.c_float)]),
+    "mi_op_gemm_prefill": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_float)]),
     "mi_op_chain": (C.c_int, [C.POINTER(C.POINTER(OpLinear)), C.POINTER(OpGemvArgs), C.POINTER(C.c_int32), C.c_int, C.c_int,
                               C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "mi_op_tiled_bytes": (C.c_uint64, [C.POINTER(OpLinear)]),

@@ -245,6 +245,47 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
   }
 }
 
+constexpr int BM2 = 256, BN2 = 256;
+
+// the epilogue of the 256 x 256 tiles (2 x 4 waves, 128 x 64 per wave): lane (c16, g) holds C[m = 4g + r][n = c16] of
+// every 16 x 16 tile
+template <typename AT, bool SWIGLU>
+__device__ __forceinline__ void tile256_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int m0, int bn, int wm, int wn, int c16, int g) {
+  AT* out = (AT*)p.out;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 128 + mt * 16 + 4 * g + r;
+      if (m >= p.M) continue;
+      if constexpr (SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = bn * 128 + wn * 32 + j * 16 + c16;
+          if (n >= p.pair_offset) continue;
+          if (p.out32) { epi32_swiglu(p, m, n, acc[mt][j][r], acc[mt][j + 2][r]); continue; }
+          const float gt = (float)(AT)acc[mt][j][r], up = (float)(AT)acc[mt][j + 2][r];
+          const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+          const float sl = (float)(AT)(gt * sig);
+          out[(size_t)m * p.ldo + n] = (AT)(sl * up);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = bn * BN2 + wn * 64 + nt * 16 + c16;
+          if (n >= p.N) continue;
+          if (p.out32) { epi32_plain(p, m, n, acc[mt][nt][r]); continue; }
+          const float y = (float)(AT)acc[mt][nt][r];
+          if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
+          else {
+            AT* h = (AT*)p.resid;
+            h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
+          }
+        }
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, 8 waves (2 in M x 4 in N, 128 x 64 per wave = 8 x 4 MFMA tiles), BOTH operands staged in
 // LDS.  Why: with W fragments read per wave from global memory the 128 x 128 kernel moves 48 KB from L2 per
@@ -254,7 +295,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
 // Double-buffered: the next step's 8 loads per thread are in flight during the current step's 64 MFMAs per wave.
 // SWIGLU: the block covers 128 gate columns and the 128 matching up columns; a wave's four N tiles are two gate
 // tiles + their up tiles.
-constexpr int BM2 = 256, BN2 = 256;
 constexpr int A2_BYTES = BM2 * LDA * 2;                 // one X image (rows padded to 144 B)
 constexpr int B2_BYTES = BN2 * BK * 2;                  // one W image: 16 row tiles x 2 k blocks x 1 KiB
 constexpr int LDS2_BYTES = 2 * (A2_BYTES + B2_BYTES);
@@ -422,40 +462,195 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
     if (ks + 1 < nk) step(ks + 1, bset1, bset0);
   }
 
-  // ---- epilogue: lane (c16, g) holds C[m = 4g + r][n = c16] of every 16 x 16 tile
-  AT* out = (AT*)p.out;
+  tile256_epilogue<AT, SWIGLU>(p, acc, m0, bn, wm, wn, c16, g);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, both operands staged by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, and
+// -- the point -- the copies of a K tile stay in flight across barriers for three to four phases (~1.5 K tiles of MFMA
+// work) instead of three quarters of one K step.  Same wave grid and accumulator layout as gemm_tile256_kernel
+// (2 x 4 waves, 128 x 64 per wave, acc[8][4]), same epilogue.
+//
+// LDS: two K-tile buffers of 64 KiB, each four UNITS of 16 KiB -- a unit is what all 8 waves stage together in one
+// phase (two 1-KiB DMA instructions per wave):
+//     A-h0 / A-h1   rows {wm * 128 + h * 64 + [0, 64)} of the X tile (128 rows x 128 B), image row ir = wm * 64 + r
+//     B-k0 / B-k1   the 16 W row tiles of k block kb: 16 fragments of 1 KiB in tile-major order (a fragment read is one
+//                   contiguous KiB: conflict-free as it lies)
+// A image: the DMA writes lane-linear (base + 16 lane), so the layout is chosen through the SOURCE address of each lane.
+// Image rows are paired into 256-byte bank rows; piece (ir, q) (q = 16-byte chunk 0..7 of the row's 128 bytes) lies at
+//     (ir >> 1) * 256 + ((((ir & 1) << 3) | q) ^ ((ir >> 1) & 7)) * 16
+// -- the 16 lanes of a fragment read group (16 consecutive rows, one q) hit 16 different 16-byte columns, and the 8
+// lanes that fill a row fetch its whole 128-byte line.
+//
+// Schedule.  A K tile is four phases of 16 MFMAs per wave: (k block, row half) = (0,0) (0,1) (1,0) (1,1).  A phase
+//   * stages ONE unit of a later tile:  j=0: A-h1(t+1)   j=1: B-k0(t+2)   j=2: A-h0(t+2)   j=3: B-k1(t+2)
+//   * reads the fragments of the NEXT phase from LDS while its own MFMAs run (A: 4 fragments; the B fragments of a k block
+//     are read once per tile: k1 during j=0, k0 of tile t+1 during j=2)
+//   * ends with  s_waitcnt lgkmcnt(0) ; s_waitcnt vmcnt(N_j) ; s_barrier.
+// Write-after-read: every LDS read issued in phase P has completed at P's closing barrier (lgkmcnt(0)); a unit is restaged
+// only in a phase after the one that issued its last read (A-h1: last read issued in j=2 of the previous tile of that
+// buffer, restaged two phases later; B-k0: read in j=2 of tile t-1, restaged in j=1 of t; A-h0: j=1 -> j=2; B-k1: j=0 -> j=3).
+// Read-after-write: a wave's DMA has landed when its counted vmcnt wait says so, everybody's when all waves have passed the
+// barrier behind that wait; the first read of a unit is issued in a LATER phase than that barrier closes:
+//     unit          staged in       first read issued in   wait at the end of    DMAs issued since (may stay in flight)
+//     B-k0(t+1)     (t-1, j=1)      (t, j=2)               (t, j=1)              4 units -> vmcnt(8)
+//     A-h0(t+1)     (t-1, j=2)      (t, j=3)               (t, j=2)              4 units -> vmcnt(8)
+//     B-k1(t+1)     (t-1, j=3)      (t+1, j=0)             (t, j=3)              3 units -> vmcnt(6)
+//     A-h1(t+1)     (t,   j=0)      (t+1, j=0)             (t, j=3)              3 units -> vmcnt(6)
+// (vmcnt counts in order, and these DMAs are the loop's only vector-memory instructions.)  Past the last tile the stages
+// repeat the last tile's sources -- straight-line, the counts stay what the table says -- into units nobody reads again.
+constexpr int DMA_BUF = 65536, DMA_UNIT = 16384;
+
+__device__ __forceinline__ void dma_kib(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+
+template <int VM>
+__device__ __forceinline__ void phase_close() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (VM >= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+}
+
+template <typename AT, bool SWIGLU>
+__global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;              // 2 x 4 waves
+  const int c16 = lane & 15, g = lane >> 4;
+  const int bm = blockIdx.x, bn = blockIdx.y;
+  const int m0 = bm * BM2;
+  const int nk = p.K / BK, nkw = p.kw / BK;
+  const int ntiles_w = p.N / 16;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem2;
+
+  auto w_tile_of = [&](int s) -> int {                   // the 16 W row tiles of this block, in LDS order (slot s)
+    int t;
+    if constexpr (!SWIGLU) t = (bn * BN2) / 16 + s;
+    else t = (bn * 128 + (s >> 2) * 32 + (s & 1) * 16 + ((s >> 1) & 1) * p.pair_offset) / 16;   // wave wn = s>>2: gate, gate, up, up
+    return min(t, ntiles_w - 1);
+  };
+
+  // ---- DMA sources.  A unit h, instruction i (0 / 1) of this wave = image rows (2 wave + i) * 8 + [0, 8) of the unit:
+  // lane -> bank row R = lane >> 4 of the instruction's four, column col = lane & 15; row in pair = col >> 3, and the
+  // chunk q it must fetch so that the linear write realises the swizzle: q = (col & 7) ^ (R & 7), R & 7 = 4 i + (lane >> 4).
+  const char* asrc[2][2];
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * 128 + mt * 16 + 4 * g + r;
-      if (m >= p.M) continue;
-      if constexpr (SWIGLU) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = bn * 128 + wn * 32 + j * 16 + c16;
-          if (n >= p.pair_offset) continue;
-          if (p.out32) { epi32_swiglu(p, m, n, acc[mt][j][r], acc[mt][j + 2][r]); continue; }
-          const float gt = (float)(AT)acc[mt][j][r], up = (float)(AT)acc[mt][j + 2][r];
-          const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
-          const float sl = (float)(AT)(gt * sig);
-          out[(size_t)m * p.ldo + n] = (AT)(sl * up);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int n = bn * BN2 + wn * 64 + nt * 16 + c16;
-          if (n >= p.N) continue;
-          if (p.out32) { epi32_plain(p, m, n, acc[mt][nt][r]); continue; }
-          const float y = (float)(AT)acc[mt][nt][r];
-          if (p.epi == EPI_STORE) out[(size_t)m * p.ldo + n] = (AT)y;
-          else {
-            AT* h = (AT*)p.resid;
-            h[(size_t)m * p.ldo + n] = (AT)((float)h[(size_t)m * p.ldo + n] + y);
-          }
-        }
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int rl = lane >> 4, col = lane & 15;
+      const int ir = (2 * wave + i) * 8 + 2 * rl + (col >> 3);            // image row of the unit: wm' * 64 + r
+      const int q = (col & 7) ^ (4 * i + rl);
+      const int row = (ir >> 6) * 128 + h * 64 + (ir & 63);                 // row of the 256-row tile
+      asrc[h][i] = (const char*)p.x + ((size_t)min(m0 + row, p.M - 1) * p.ldx + q * 8) * sizeof(AT);
     }
+  const char* bsrc[2];                                                     // B unit: fragment slots 2 wave, 2 wave + 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bsrc[i] = (const char*)p.w + (size_t)w_tile_of(2 * wave + i) * (p.kw / 32) * 1024 + lane * 16;
+
+  auto stage_a = [&](int t, int h) {                     // unit A-h of tile t -> buffer t & 1
+    const int ts = min(t, nk - 1);
+    const size_t koff = (size_t)((ts * BK) % p.ka) * sizeof(AT);
+    const unsigned dst = lds0 + (t & 1) * DMA_BUF + h * DMA_UNIT + wave * 2048;
+    dma_kib(asrc[h][0] + koff, dst);
+    dma_kib(asrc[h][1] + koff, dst + 1024);
+  };
+  auto stage_b = [&](int t, int kb) {                    // unit B-kb of tile t
+    const int ts = min(t, nk - 1);
+    const size_t koff = (size_t)((ts % nkw) * 2 + kb) * 1024;
+    const unsigned dst = lds0 + (t & 1) * DMA_BUF + (2 + kb) * DMA_UNIT + wave * 2048;
+    dma_kib(bsrc[0] + koff, dst);
+    dma_kib(bsrc[1] + koff, dst + 1024);
+  };
+
+  // ---- fragment reads.  A (kb, h, mt4): image row wm * 64 + mt4 * 16 + c16, chunk kb * 4 + g
+  const unsigned a_lane = lds0 + (unsigned)((wm * 32 + (c16 >> 1)) * 256 + (((((c16 & 1) << 3) | g) ^ (c16 >> 1)) * 16));
+  const unsigned b_lane = lds0 + 2 * DMA_UNIT + (unsigned)(wn * 4 * 1024 + lane * 16);
+  auto a_frags = [&](int t, int kb, int h, u32x4 (&dst)[4]) {
+    const unsigned base = (a_lane ^ (unsigned)(kb << 6)) + (t & 1) * DMA_BUF + h * DMA_UNIT;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const lds_u32x4_t*)(size_t)(base + mt * 8 * 256);
+  };
+  auto b_frags = [&](int t, int kb, u32x4 (&dst)[4]) {
+    const unsigned base = b_lane + (t & 1) * DMA_BUF + kb * DMA_UNIT;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dst[nt] = *(const lds_u32x4_t*)(size_t)(base + nt * 1024);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 af[2][4], bf[2][4];
+
+  auto mma = [&](int h, const u32x4 (&a)[4], const u32x4 (&b)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[h * 4 + mt][nt] = mfma16<AT>(a[mt], b[nt], acc[h * 4 + mt][nt]);
+  };
+
+  // ---- prologue: tile 0 whole, then what the phases of tiles -2 / -1 would have staged, in their order
+  stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
+  stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  b_frags(0, 0, bf[0]);
+  a_frags(0, 0, 0, af[0]);
+
+  // The order inside a phase is pinned (sched_barrier): the DMA issue and the LDS reads for the NEXT phase first, then this
+  // phase's 16 MFMAs -- they only use registers that the previous phase loaded, so the reads complete in their shadow and
+  // the lgkmcnt(0) of the close costs nothing.  Left alone hipcc floats the MFMAs across the phase ends (they touch no
+  // memory) and sinks each read to just in front of its MFMA: four exposed LDS round trips per tile.
+#define PHASE_TOP() __builtin_amdgcn_sched_barrier(0)
+#define PHASE_MID() __builtin_amdgcn_sched_barrier(0)
+  for (int t = 0; t < nk; ++t) {
+    // j = 0: (k0, h0)
+    PHASE_TOP();
+    stage_a(t + 1, 1);
+    a_frags(t, 0, 1, af[1]);
+    b_frags(t, 1, bf[1]);
+    PHASE_MID();
+    mma(0, af[0], bf[0]);
+    PHASE_MID();
+    phase_close<-1>();
+    // j = 1: (k0, h1)
+    PHASE_TOP();
+    stage_b(t + 2, 0);
+    a_frags(t, 1, 0, af[0]);
+    PHASE_MID();
+    mma(1, af[1], bf[0]);
+    PHASE_MID();
+    phase_close<8>();
+    // j = 2: (k1, h0)
+    PHASE_TOP();
+    stage_a(t + 2, 0);
+    a_frags(t, 1, 1, af[1]);
+    b_frags(t + 1, 0, bf[0]);
+    PHASE_MID();
+    mma(0, af[0], bf[1]);
+    PHASE_MID();
+    phase_close<8>();
+    // j = 3: (k1, h1)
+    PHASE_TOP();
+    stage_b(t + 2, 1);
+    a_frags(t + 1, 0, 0, af[0]);
+    PHASE_MID();
+    mma(1, af[1], bf[1]);
+    PHASE_MID();
+    phase_close<6>();
+  }
+#undef PHASE_TOP
+#undef PHASE_MID
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA of this workgroup may land after it has left the CU
+
+  tile256_epilogue<AT, SWIGLU>(p, acc, m0, bn, wm, wn, c16, g);
 }
 
 
@@ -878,8 +1073,14 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     const int bn = sw ? 128 : BN2;
     const dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
     static const bool m32 = getenv("MI_GEMM_M32") != nullptr;               // A/B: the 32x32x16 form of the tile
+    const char* dma_env = getenv("MI_GEMM_DMA");       // A/B and the bit-equality test: 0 = the register-staged tile (read per call)
+    const bool dma = dma_env == nullptr || atoi(dma_env) != 0;
+    const bool use_dma = dma && p.K >= 2 * BK;
 #define GO256(T, S) do { \
-      if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \
+      if (use_dma) { auto k = gemm_dma256_kernel<T, S>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DMA_BUF)); \
+        hipLaunchKernelGGL(k, grid2, block2, 2 * DMA_BUF, st, p); } \
+      else if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
         hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } \
       else if (b_in_lds) { auto k = gemm_tile256_kernel<T, S, false>; \

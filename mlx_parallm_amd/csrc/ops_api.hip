@@ -110,6 +110,30 @@ int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int kspli
   return rc != MI_OK ? rc : rc2;
 }
 
+int mi_op_gemm_prefill(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms) {
+  if (!w || !a) return fail(MI_ERR_INVALID, "null argument");
+  MI_TRY(ready());
+  const LinearW W = to_linear(w);
+  const GemvCall c = to_call(a);
+  if (c.M < 1 || c.pro != PRO_NONE || W.layout != 1 || wk_is_quant(W.wk) || c.act == MI_F32)
+    return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_prefill: tile-major dense 16-bit weights, 16-bit activations, no prologue");
+  int rc = launch_gemm_prefill(W, c, (size_t)c.M, nullptr, nullptr, nullptr, 0);
+  if (rc == MI_OK && iters >= 1 && avg_ms) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && rc == MI_OK; ++i) rc = launch_gemm_prefill(W, c, (size_t)c.M, nullptr, nullptr, nullptr, 0);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *avg_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  const int rc2 = finish();
+  return rc != MI_OK ? rc : rc2;
+}
+
 int mi_op_chain(const mi_op_linear* const* w, const mi_op_gemv_args* a, const int32_t* wait_prev, int nops, int iters,
                 float* avg_ms, int32_t* error_out) {
   if (!w || !a || !wait_prev || nops < 1 || nops > 4) return fail(MI_ERR_INVALID, "bad argument");

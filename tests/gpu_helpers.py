@@ -125,3 +125,12 @@ def gemm_skinny(ol: L.OpLinear, x, M, act, *, epi=0, out=None, ldo=0, resid=None
     used, ms = C.c_int(0), C.c_float(0.0)
     L.check(L.lib().mi_op_gemm_skinny(C.byref(ol), C.byref(a), int(ksplit), C.byref(used), int(iters), C.byref(ms)))
     return used.value, (ms.value if iters >= 1 else None)
+
+
+def gemm_prefill(ol: L.OpLinear, x, M, act, *, epi=0, out=None, ldo=0, resid=None, pair_offset=0, iters=0, ldx=None):
+    """gemm_prefill.hip on its own (the tile GEMM of the prefill call) -> mean launch ms or None."""
+    a = gemv_args(x, M, act, epi=epi, out=out, ldo=ldo, resid=resid, pair_offset=pair_offset, ldx=ldx)
+    torch.cuda.synchronize()
+    ms = C.c_float(0.0)
+    L.check(L.lib().mi_op_gemm_prefill(C.byref(ol), C.byref(a), int(iters), C.byref(ms)))
+    return ms.value if iters >= 1 else None

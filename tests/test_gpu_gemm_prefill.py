@@ -1,0 +1,104 @@
+"""Kernel-level parity (-m gpu) of gemm_prefill.hip's 256 x 256 tile -- the GEMM of the prefill call (generate_step's
+first model call, utils.py:243-262 -> every nn.Linear over B x L rows, llama.py:64-67,93,143,160-165) -- through
+mi_op_gemm_prefill (include/mi355_ops.h): against the oracle's matmul on sampled rows, and the LDS-DMA kernel bit for bit
+against the register-staged kernel it replaced (same MFMA chain per accumulator, so the float32 sums must be identical)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.numerics import matmul_nt, round_to
+
+pytestmark = pytest.mark.gpu
+
+from mlx_parallm_amd import _lib as L  # noqa: E402
+from gpu_helpers import dev, gemm_prefill, host, op_linear, to_tiled  # noqa: E402
+from test_gpu_kernels import _assert_close  # noqa: E402
+
+RNG = np.random.default_rng(777)
+
+
+def _weight(kind, N, K):
+    dt = {"bf16": "bfloat16", "f16": "float16"}[kind]
+    w = round_to(RNG.standard_normal((N, K)).astype(np.float32) * 0.05, dt)
+    wd = dev(w, dt)
+    ol, keep = op_linear(kind, N, K, wd), [wd]
+    assert to_tiled(ol, keep)
+    return ol, w, keep
+
+
+def _run(ol, xd, M, act, dma, **kw):
+    old = os.environ.get("MI_GEMM_DMA")
+    os.environ["MI_GEMM_DMA"] = "1" if dma else "0"
+    try:
+        gemm_prefill(ol, xd, M, act, **kw)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["MI_GEMM_DMA"]
+        else:
+            os.environ["MI_GEMM_DMA"] = old
+
+
+def _rows(M):
+    """the ragged last block whole, the first rows, and a few from the middle"""
+    pick = set(range(min(M, 20))) | set(range(max(0, (M - 1) // 256 * 256), M)) | set(RNG.integers(0, M, 24).tolist())
+    return np.array(sorted(pick))
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "bf16"), ("float16", "f16")])
+@pytest.mark.parametrize("M,N,K", [
+    (2085, 6144, 512),       # 9 x 24 blocks, ragged last row block (37 rows)
+    (2048, 6400, 128),       # two K tiles: prologue and tail only
+    (2304, 5632, 192),       # odd number of K tiles
+    (4096, 4096, 1024),      # 16 x 16 blocks, 16 K tiles
+])
+def test_store_and_residual_match_oracle_and_the_register_staged_tile(act, kind, M, N, K):
+    ol, w, keep = _weight(kind, N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    h0 = round_to(RNG.standard_normal((M, N)).astype(np.float32), act)
+    xd = dev(x, act)
+    rows = _rows(M)
+    want = round_to(matmul_nt(x[rows], w), act)
+    got = {}
+    for dma in (True, False):
+        out = torch.full((M + 3, N), 7.0, dtype=xd.dtype, device="cuda")
+        _run(ol, xd, M, act, dma, epi=L.EPI_STORE, out=out, ldo=N)
+        o = host(out)
+        assert np.all(o[M:] == 7.0), "rows past M were written"
+        got[dma] = o[:M]
+    _assert_close(got[True][rows], want, act)
+    assert np.array_equal(got[True], got[False]), "LDS-DMA tile differs from the register-staged tile"
+    # residual epilogue: h += y, in place
+    hres = {}
+    for dma in (True, False):
+        h = dev(h0, act)
+        _run(ol, xd, M, act, dma, epi=L.EPI_RESID, resid=h, out=h, ldo=N)
+        hres[dma] = host(h)
+    y = round_to(matmul_nt(x[rows], w), act)
+    _assert_close(hres[True][rows], round_to(h0[rows] + y, act), act)
+    assert np.array_equal(hres[True], hres[False])
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "bf16"), ("float16", "f16")])
+@pytest.mark.parametrize("M,I,K", [(2085, 3072, 512), (2048, 3200, 256)])
+def test_swiglu_matches_oracle_and_the_register_staged_tile(act, kind, M, I, K):
+    ol, w, keep = _weight(kind, 2 * I, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    xd = dev(x, act)
+    rows = _rows(M)
+    y = round_to(matmul_nt(x[rows], w), act)
+    gt, up = y[:, :I].astype(np.float64), y[:, I:]
+    sig = round_to((1.0 / (1.0 + np.exp(-gt))).astype(np.float32), act)
+    sl = round_to(gt.astype(np.float32) * sig, act)
+    want = round_to(sl * up, act)
+    got = {}
+    for dma in (True, False):
+        out = torch.full((M + 1, I), 7.0, dtype=xd.dtype, device="cuda")
+        _run(ol, xd, M, act, dma, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I)
+        o = host(out)
+        assert np.all(o[M:] == 7.0)
+        got[dma] = o[:M]
+    _assert_close(got[True][rows], want, act, scale=float(np.abs(y).max()))
+    assert np.array_equal(got[True], got[False]), "LDS-DMA tile differs from the register-staged tile"
