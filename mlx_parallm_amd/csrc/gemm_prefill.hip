@@ -516,7 +516,7 @@ __device__ __forceinline__ void phase_close() {
   asm volatile("s_barrier" ::: "memory");
 }
 
-template <typename AT, bool SWIGLU>
+template <typename AT, bool SWIGLU, int SCHED>
 __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -553,34 +553,38 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) bsrc[i] = (const char*)p.w + (size_t)w_tile_of(2 * wave + i) * (p.kw / 32) * 1024 + lane * 16;
 
-  auto stage_a = [&](int t, int h) {                     // unit A-h of tile t -> buffer t & 1
+  // unit A-h / B-kb of tile t (sources past the last tile repeat it) -> the 16 KiB at LDS byte offset `off`
+  auto stage_a_at = [&](int t, int h, unsigned off) {
     const int ts = min(t, nk - 1);
     const size_t koff = (size_t)((ts * BK) % p.ka) * sizeof(AT);
-    const unsigned dst = lds0 + (t & 1) * DMA_BUF + h * DMA_UNIT + wave * 2048;
+    const unsigned dst = lds0 + off + wave * 2048;
     dma_kib(asrc[h][0] + koff, dst);
     dma_kib(asrc[h][1] + koff, dst + 1024);
   };
-  auto stage_b = [&](int t, int kb) {                    // unit B-kb of tile t
+  auto stage_b_at = [&](int t, int kb, unsigned off) {
     const int ts = min(t, nk - 1);
     const size_t koff = (size_t)((ts % nkw) * 2 + kb) * 1024;
-    const unsigned dst = lds0 + (t & 1) * DMA_BUF + (2 + kb) * DMA_UNIT + wave * 2048;
+    const unsigned dst = lds0 + off + wave * 2048;
     dma_kib(bsrc[0] + koff, dst);
     dma_kib(bsrc[1] + koff, dst + 1024);
   };
-
-  // ---- fragment reads.  A (kb, h, mt4): image row wm * 64 + mt4 * 16 + c16, chunk kb * 4 + g
+  // ---- fragment reads.  A (kb, mt4) of the unit at `off`: image row wm * 64 + mt4 * 16 + c16, chunk kb * 4 + g
   const unsigned a_lane = lds0 + (unsigned)((wm * 32 + (c16 >> 1)) * 256 + (((((c16 & 1) << 3) | g) ^ (c16 >> 1)) * 16));
-  const unsigned b_lane = lds0 + 2 * DMA_UNIT + (unsigned)(wn * 4 * 1024 + lane * 16);
-  auto a_frags = [&](int t, int kb, int h, u32x4 (&dst)[4]) {
-    const unsigned base = (a_lane ^ (unsigned)(kb << 6)) + (t & 1) * DMA_BUF + h * DMA_UNIT;
+  const unsigned b_lane = lds0 + (unsigned)(wn * 4 * 1024 + lane * 16);
+  auto a_frags_at = [&](unsigned off, int kb, u32x4 (&dst)[4]) {
+    const unsigned base = (a_lane ^ (unsigned)(kb << 6)) + off;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const lds_u32x4_t*)(size_t)(base + mt * 8 * 256);
   };
-  auto b_frags = [&](int t, int kb, u32x4 (&dst)[4]) {
-    const unsigned base = b_lane + (t & 1) * DMA_BUF + kb * DMA_UNIT;
+  auto b_frags_at = [&](unsigned off, u32x4 (&dst)[4]) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) dst[nt] = *(const lds_u32x4_t*)(size_t)(base + nt * 1024);
+    for (int nt = 0; nt < 4; ++nt) dst[nt] = *(const lds_u32x4_t*)(size_t)(b_lane + off + nt * 1024);
   };
+  // two K-tile buffers (SCHED 0 / 1): tile t in buffer t & 1 = [A-h0][A-h1][B-k0][B-k1]
+  auto stage_a = [&](int t, int h) { stage_a_at(t, h, (t & 1) * DMA_BUF + h * DMA_UNIT); };
+  auto stage_b = [&](int t, int kb) { stage_b_at(t, kb, (t & 1) * DMA_BUF + (2 + kb) * DMA_UNIT); };
+  auto a_frags = [&](int t, int kb, int h, u32x4 (&dst)[4]) { a_frags_at((t & 1) * DMA_BUF + h * DMA_UNIT, kb, dst); };
+  auto b_frags = [&](int t, int kb, u32x4 (&dst)[4]) { b_frags_at((t & 1) * DMA_BUF + (2 + kb) * DMA_UNIT, dst); };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -596,58 +600,137 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
       for (int nt = 0; nt < 4; ++nt) acc[h * 4 + mt][nt] = mfma16<AT>(a[mt], b[nt], acc[h * 4 + mt][nt]);
   };
 
-  // ---- prologue: tile 0 whole, then what the phases of tiles -2 / -1 would have staged, in their order
-  stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
-  stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  asm volatile("s_barrier" ::: "memory");
-  b_frags(0, 0, bf[0]);
-  a_frags(0, 0, 0, af[0]);
+  if constexpr (SCHED == 1) {
+    // ---- ping-pong: the two waves of a SIMD (w and w + 4) run half a phase apart -- while one issues its DMA and reads the
+    // fragments of its phase, the other has the matrix core.  A phase is [stage, reads, waits] barrier [16 MFMAs] barrier;
+    // waves 4..7 enter through one extra barrier (and waves 0..3 leave through one), so every s_barrier pairs the end of one
+    // group's read section with the end of the other's MFMA section.  Reads are for the SAME phase (one fragment set).
+    //   stage:  j=0: A-h1(t+1)   j=1: B-k0(t+2)   j=2: B-k1(t+1)   j=3: A-h0(t+2)
+    // Write-after-read: a unit last read in phase Q (both groups' reads have completed two barriers later) is restaged in
+    // phase Q + 1 at the earliest (A-h0: read (t,0) (t,2) -> (t,3); A-h1: (t,1) (t,3) -> (t+1,0); B-k0: (t,0) -> (t,1);
+    // B-k1: (t,2) -> (t+1,2)).  Read-after-write: waited for in the read section of phase W, first read in phase W + 1:
+    //     unit          staged in     waited for in   first read in   DMAs issued since
+    //     A-h1(t+1)     (t, j=0)      (t+1, j=0)      (t+1, j=1)      4 units -> vmcnt(8)
+    //     B-k1(t+1)     (t, j=2)      (t+1, j=1)      (t+1, j=2)      3 units -> vmcnt(6)
+    //     B-k0(t+2)     (t, j=1)      (t+1, j=3)      (t+2, j=0)      (in order: landed before A-h0(t+2))
+    //     A-h0(t+2)     (t, j=3)      (t+1, j=3)      (t+2, j=0)      4 units -> vmcnt(8)
+    stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(1, 0); stage_b(0, 1); stage_a(1, 0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+#define PP_READS_DONE(VM) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+      if (VM >= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM < 0 ? 0 : VM) : "memory"); \
+      asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
+#define PP_MMA_DONE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); asm volatile("s_barrier" ::: "memory"); \
+      __builtin_amdgcn_sched_barrier(0); } while (0)
+    // (reads before the DMA issue: an LDS-DMA instruction holds the wave's issue for 60..180 cycles -- the fragments arrive
+    // meanwhile, and the lgkmcnt(0) of the close finds them there)
+#define PP_ORDER() __builtin_amdgcn_sched_barrier(0)
+    for (int t = 0; t < nk; ++t) {
+      b_frags(t, 0, bf[0]); a_frags(t, 0, 0, af[0]); PP_ORDER(); stage_a(t + 1, 1);
+      PP_READS_DONE(8);
+      mma(0, af[0], bf[0]);
+      PP_MMA_DONE();
+      a_frags(t, 0, 1, af[0]); PP_ORDER(); stage_b(t + 2, 0);
+      PP_READS_DONE(6);
+      mma(1, af[0], bf[0]);
+      PP_MMA_DONE();
+      b_frags(t, 1, bf[1]); a_frags(t, 1, 0, af[0]); PP_ORDER(); stage_b(t + 1, 1);
+      PP_READS_DONE(-1);
+      mma(0, af[0], bf[1]);
+      PP_MMA_DONE();
+      a_frags(t, 1, 1, af[0]); PP_ORDER(); stage_a(t + 2, 0);
+      PP_READS_DONE(8);
+      mma(1, af[0], bf[1]);
+      PP_MMA_DONE();
+    }
+#undef PP_ORDER
+#undef PP_READS_DONE
+#undef PP_MMA_DONE
+    if (wave < 4) asm volatile("s_barrier" ::: "memory");
+  } else if constexpr (SCHED == 2) {
+    // ---- ping-pong over all 160 KiB of LDS: the A units of consecutive tiles go round a ring of FIVE 16-KiB slots (unit
+    // a = 2 t + h in slot a mod 5), the B units round another (b = 2 t + kb) -- 2.5 tiles of each operand instead of 2, and
+    // every unit is staged a whole tile earlier than with two tile buffers: five to seven phases in flight instead of three
+    // or four.  (With the DMA issue moved HALF a phase later the two-buffer form lost 6 %: the copies' latency is not fully
+    // covered there.)
+    //   stage (all of tile t + 2):  j=0: B-k0   j=1: A-h0   j=2: B-k1   j=3: A-h1
+    // Write-after-read (restage in phase Q + 1 at the earliest, Q = last phase that reads the slot's old unit):
+    //     B-k0(t+2) -> slot of B-k1(t-1), last read (t-1, 2)        A-h0(t+2) -> slot of A-h1(t-1), last read (t-1, 3)
+    //     B-k1(t+2) -> slot of B-k0(t),   last read (t, 0)          A-h1(t+2) -> slot of A-h0(t),   last read (t, 2): staged (t, 3)
+    // Read-after-write (waited for in the read section of phase W, first read in W + 1 or later):
+    //     unit          staged in     waited for in   first read in   DMAs issued since
+    //     B-k0(t+2)     (t, j=0)      (t+1, j=3)      (t+2, j=0)      (in order: landed before A-h0(t+2))
+    //     A-h0(t+2)     (t, j=1)      (t+1, j=3)      (t+2, j=0)      6 units -> vmcnt(12)
+    //     B-k1(t+2)     (t, j=2)      (t+2, j=0)      (t+2, j=2)      (in order: landed before A-h1(t+2))
+    //     A-h1(t+2)     (t, j=3)      (t+2, j=0)      (t+2, j=1)      5 units -> vmcnt(10)
+    constexpr unsigned RB = 5 * DMA_UNIT;                  // the B ring starts behind the A ring
+    auto slot = [&](int s5, int d) -> unsigned { const int v = s5 + d; return (unsigned)(v >= 10 ? v - 10 : v >= 5 ? v - 5 : v) * DMA_UNIT; };
+    // tiles 0 and 1 whole, in the order the phases of tiles -2 / -1 would have staged them (units a, b = 0..3 in slots 0..3)
+    stage_b_at(0, 0, RB + 0 * DMA_UNIT); stage_a_at(0, 0, 0 * DMA_UNIT); stage_b_at(0, 1, RB + 1 * DMA_UNIT); stage_a_at(0, 1, 1 * DMA_UNIT);
+    stage_b_at(1, 0, RB + 2 * DMA_UNIT); stage_a_at(1, 0, 2 * DMA_UNIT); stage_b_at(1, 1, RB + 3 * DMA_UNIT); stage_a_at(1, 1, 3 * DMA_UNIT);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+#define PP_READS_DONE(VM) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+      if (VM >= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM < 0 ? 0 : VM) : "memory"); \
+      asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
+#define PP_MMA_DONE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); asm volatile("s_barrier" ::: "memory"); \
+      __builtin_amdgcn_sched_barrier(0); } while (0)
+    int s5 = 0;                                            // (2 t) mod 5
+    for (int t = 0; t < nk; ++t) {
+      stage_b_at(t + 2, 0, RB + slot(s5, 4)); b_frags_at(RB + slot(s5, 0), bf[0]); a_frags_at(slot(s5, 0), 0, af[0]);
+      PP_READS_DONE(10);
+      mma(0, af[0], bf[0]);
+      PP_MMA_DONE();
+      stage_a_at(t + 2, 0, slot(s5, 4)); a_frags_at(slot(s5, 1), 0, af[0]);
+      PP_READS_DONE(-1);
+      mma(1, af[0], bf[0]);
+      PP_MMA_DONE();
+      stage_b_at(t + 2, 1, RB + slot(s5, 5)); b_frags_at(RB + slot(s5, 1), bf[1]); a_frags_at(slot(s5, 0), 1, af[0]);
+      PP_READS_DONE(-1);
+      mma(0, af[0], bf[1]);
+      PP_MMA_DONE();
+      stage_a_at(t + 2, 1, slot(s5, 5)); a_frags_at(slot(s5, 1), 1, af[0]);
+      PP_READS_DONE(12);
+      mma(1, af[0], bf[1]);
+      PP_MMA_DONE();
+      s5 = s5 + 2 >= 5 ? s5 - 3 : s5 + 2;
+    }
+#undef PP_READS_DONE
+#undef PP_MMA_DONE
+    if (wave < 4) asm volatile("s_barrier" ::: "memory");
+  } else {
+    // ---- prologue: tile 0 whole, then what the phases of tiles -2 / -1 would have staged, in their order
+    stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
+    stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    b_frags(0, 0, bf[0]);
+    a_frags(0, 0, 0, af[0]);
 
-  // The order inside a phase is pinned (sched_barrier): the DMA issue and the LDS reads for the NEXT phase first, then this
-  // phase's 16 MFMAs -- they only use registers that the previous phase loaded, so the reads complete in their shadow and
-  // the lgkmcnt(0) of the close costs nothing.  Left alone hipcc floats the MFMAs across the phase ends (they touch no
-  // memory) and sinks each read to just in front of its MFMA: four exposed LDS round trips per tile.
-#define PHASE_TOP() __builtin_amdgcn_sched_barrier(0)
-#define PHASE_MID() __builtin_amdgcn_sched_barrier(0)
-  for (int t = 0; t < nk; ++t) {
-    // j = 0: (k0, h0)
-    PHASE_TOP();
-    stage_a(t + 1, 1);
-    a_frags(t, 0, 1, af[1]);
-    b_frags(t, 1, bf[1]);
-    PHASE_MID();
-    mma(0, af[0], bf[0]);
-    PHASE_MID();
-    phase_close<-1>();
-    // j = 1: (k0, h1)
-    PHASE_TOP();
-    stage_b(t + 2, 0);
-    a_frags(t, 1, 0, af[0]);
-    PHASE_MID();
-    mma(1, af[1], bf[0]);
-    PHASE_MID();
-    phase_close<8>();
-    // j = 2: (k1, h0)
-    PHASE_TOP();
-    stage_a(t + 2, 0);
-    a_frags(t, 1, 1, af[1]);
-    b_frags(t + 1, 0, bf[0]);
-    PHASE_MID();
-    mma(0, af[0], bf[1]);
-    PHASE_MID();
-    phase_close<8>();
-    // j = 3: (k1, h1)
-    PHASE_TOP();
-    stage_b(t + 2, 1);
-    a_frags(t + 1, 0, 0, af[0]);
-    PHASE_MID();
-    mma(1, af[1], bf[1]);
-    PHASE_MID();
-    phase_close<6>();
+    // The order inside a phase is pinned (sched_barrier): the DMA issue and the LDS reads for the NEXT phase first, then this
+    // phase's 16 MFMAs -- they only use registers that the previous phase loaded, so the reads complete in their shadow and
+    // the lgkmcnt(0) of the close costs nothing.  Left alone hipcc floats the MFMAs across the phase ends (they touch no
+    // memory) and sinks each read to just in front of its MFMA: four exposed LDS round trips per tile.
+    // (Measured and dropped: waves 4..7 running a phase as [stage, MFMAs, reads] so that the two waves of a SIMD take the
+    // matrix core in turn inside one barrier interval -- 10 % slower than this lockstep form; the ping-pong above, with its
+    // second barrier per phase, is what gains.)
+  #define PHASE(STAGE, READS, MMA, VM) do { \
+      __builtin_amdgcn_sched_barrier(0); \
+      STAGE; READS; \
+      __builtin_amdgcn_sched_barrier(0); \
+      MMA; \
+      __builtin_amdgcn_sched_barrier(0); \
+      phase_close<VM>(); } while (0)
+    for (int t = 0; t < nk; ++t) {
+      PHASE(stage_a(t + 1, 1), a_frags(t, 0, 1, af[1]); b_frags(t, 1, bf[1]), mma(0, af[0], bf[0]), -1);   // j = 0: (k0, h0)
+      PHASE(stage_b(t + 2, 0), a_frags(t, 1, 0, af[0]), mma(1, af[1], bf[0]), 8);                           // j = 1: (k0, h1)
+      PHASE(stage_a(t + 2, 0), a_frags(t, 1, 1, af[1]); b_frags(t + 1, 0, bf[0]), mma(0, af[0], bf[1]), 8); // j = 2: (k1, h0)
+      PHASE(stage_b(t + 2, 1), a_frags(t + 1, 0, 0, af[0]), mma(1, af[1], bf[1]), 6);                       // j = 3: (k1, h1)
+    }
+  #undef PHASE
   }
-#undef PHASE_TOP
-#undef PHASE_MID
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA of this workgroup may land after it has left the CU
 
   tile256_epilogue<AT, SWIGLU>(p, acc, m0, bn, wm, wn, c16, g);
@@ -1075,9 +1158,16 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     static const bool m32 = getenv("MI_GEMM_M32") != nullptr;               // A/B: the 32x32x16 form of the tile
     const char* dma_env = getenv("MI_GEMM_DMA");       // A/B and the bit-equality test: 0 = the register-staged tile (read per call)
     const bool dma = dma_env == nullptr || atoi(dma_env) != 0;
+    const int dma_sched = dma_env == nullptr ? 0 : std::max(0, atoi(dma_env) - 1);   // 1 = lockstep phases, 2.. = the ping-pong schedules
     const bool use_dma = dma && p.K >= 2 * BK;
 #define GO256(T, S) do { \
-      if (use_dma) { auto k = gemm_dma256_kernel<T, S>; \
+      if (use_dma && dma_sched == 1) { auto k = gemm_dma256_kernel<T, S, 1>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DMA_BUF)); \
+        hipLaunchKernelGGL(k, grid2, block2, 2 * DMA_BUF, st, p); } \
+      else if (use_dma && dma_sched == 2) { auto k = gemm_dma256_kernel<T, S, 2>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * DMA_UNIT)); \
+        hipLaunchKernelGGL(k, grid2, block2, 10 * DMA_UNIT, st, p); } \
+      else if (use_dma) { auto k = gemm_dma256_kernel<T, S, 0>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DMA_BUF)); \
         hipLaunchKernelGGL(k, grid2, block2, 2 * DMA_BUF, st, p); } \
       else if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \

@@ -17,6 +17,7 @@ from gpu_helpers import dev, gemm_prefill, host, op_linear, to_tiled  # noqa: E4
 from test_gpu_kernels import _assert_close  # noqa: E402
 
 RNG = np.random.default_rng(777)
+MODES = (1, 2, 3)      # MI_GEMM_DMA: 1 = lockstep phases, 2 = ping-pong, 3 = ping-pong over a ring of five units; 0 = the register-staged tile
 
 
 def _weight(kind, N, K):
@@ -30,7 +31,7 @@ def _weight(kind, N, K):
 
 def _run(ol, xd, M, act, dma, **kw):
     old = os.environ.get("MI_GEMM_DMA")
-    os.environ["MI_GEMM_DMA"] = "1" if dma else "0"
+    os.environ["MI_GEMM_DMA"] = str(int(dma))
     try:
         gemm_prefill(ol, xd, M, act, **kw)
         torch.cuda.synchronize()
@@ -62,23 +63,25 @@ def test_store_and_residual_match_oracle_and_the_register_staged_tile(act, kind,
     rows = _rows(M)
     want = round_to(matmul_nt(x[rows], w), act)
     got = {}
-    for dma in (True, False):
+    for dma in MODES + (0,):
         out = torch.full((M + 3, N), 7.0, dtype=xd.dtype, device="cuda")
         _run(ol, xd, M, act, dma, epi=L.EPI_STORE, out=out, ldo=N)
         o = host(out)
         assert np.all(o[M:] == 7.0), "rows past M were written"
         got[dma] = o[:M]
-    _assert_close(got[True][rows], want, act)
-    assert np.array_equal(got[True], got[False]), "LDS-DMA tile differs from the register-staged tile"
+    _assert_close(got[1][rows], want, act)
+    for m in MODES:
+        assert np.array_equal(got[m], got[0]), f"LDS-DMA tile (MI_GEMM_DMA={m}) differs from the register-staged tile"
     # residual epilogue: h += y, in place
     hres = {}
-    for dma in (True, False):
+    for dma in MODES + (0,):
         h = dev(h0, act)
         _run(ol, xd, M, act, dma, epi=L.EPI_RESID, resid=h, out=h, ldo=N)
         hres[dma] = host(h)
     y = round_to(matmul_nt(x[rows], w), act)
-    _assert_close(hres[True][rows], round_to(h0[rows] + y, act), act)
-    assert np.array_equal(hres[True], hres[False])
+    _assert_close(hres[1][rows], round_to(h0[rows] + y, act), act)
+    for m in MODES:
+        assert np.array_equal(hres[m], hres[0]), f"MI_GEMM_DMA={m}"
 
 
 @pytest.mark.parametrize("act,kind", [("bfloat16", "bf16"), ("float16", "f16")])
@@ -94,11 +97,12 @@ def test_swiglu_matches_oracle_and_the_register_staged_tile(act, kind, M, I, K):
     sl = round_to(gt.astype(np.float32) * sig, act)
     want = round_to(sl * up, act)
     got = {}
-    for dma in (True, False):
+    for dma in MODES + (0,):
         out = torch.full((M + 1, I), 7.0, dtype=xd.dtype, device="cuda")
         _run(ol, xd, M, act, dma, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I)
         o = host(out)
         assert np.all(o[M:] == 7.0)
         got[dma] = o[:M]
-    _assert_close(got[True][rows], want, act, scale=float(np.abs(y).max()))
-    assert np.array_equal(got[True], got[False]), "LDS-DMA tile differs from the register-staged tile"
+    _assert_close(got[1][rows], want, act, scale=float(np.abs(y).max()))
+    for m in MODES:
+        assert np.array_equal(got[m], got[0]), f"LDS-DMA tile (MI_GEMM_DMA={m}) differs from the register-staged tile"
