@@ -467,10 +467,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 tile, both operands staged by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, and
-// -- the point -- the copies of a K tile stay in flight across barriers for three to four phases (~1.5 K tiles of MFMA
-// work) instead of three quarters of one K step.  Same wave grid and accumulator layout as gemm_tile256_kernel
-// (2 x 4 waves, 128 x 64 per wave, acc[8][4]), same epilogue.
+// 256 x 256 x 64 tile, both operands staged by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, the
+// copies of a K tile stay in flight across barriers for three to four phases, and the two waves of a SIMD take the matrix
+// core in turn.  Same wave grid and accumulator layout as gemm_tile256_kernel (2 x 4 waves, 128 x 64 per wave,
+// acc[8][4]), same MFMA chain per accumulator (so the same float32 sums, bit for bit), same epilogue.
+// Mistral-7B linears over 8 x 1024 rows, random bf16 operands, interleaved rounds in one process (tools/debug/
+// gemm_prefill_ab.py): 1.15 / 1.03 / 1.15 / 1.14 PFLOP/s (q|k|v, o, gate|up, down) on the register-staged tile,
+// 1.38 / 1.17 / 1.35 / 1.38 here.
 //
 // LDS: two K-tile buffers of 64 KiB, each four UNITS of 16 KiB -- a unit is what all 8 waves stage together in one
 // phase (two 1-KiB DMA instructions per wave):
@@ -480,26 +483,34 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmParams p) {
 // A image: the DMA writes lane-linear (base + 16 lane), so the layout is chosen through the SOURCE address of each lane.
 // Image rows are paired into 256-byte bank rows; piece (ir, q) (q = 16-byte chunk 0..7 of the row's 128 bytes) lies at
 //     (ir >> 1) * 256 + ((((ir & 1) << 3) | q) ^ ((ir >> 1) & 7)) * 16
-// -- the 16 lanes of a fragment read group (16 consecutive rows, one q) hit 16 different 16-byte columns, and the 8
-// lanes that fill a row fetch its whole 128-byte line.
+// -- every lane group of a ds_read_b128 fragment read ({0-3, 12-15, 20-27}, ... : 16 rows x one or two q) hits 16
+// different 16-byte columns (checked exhaustively), and the 8 lanes that fill a row fetch its whole 128-byte line.
 //
-// Schedule.  A K tile is four phases of 16 MFMAs per wave: (k block, row half) = (0,0) (0,1) (1,0) (1,1).  A phase
-//   * stages ONE unit of a later tile:  j=0: A-h1(t+1)   j=1: B-k0(t+2)   j=2: A-h0(t+2)   j=3: B-k1(t+2)
-//   * reads the fragments of the NEXT phase from LDS while its own MFMAs run (A: 4 fragments; the B fragments of a k block
-//     are read once per tile: k1 during j=0, k0 of tile t+1 during j=2)
-//   * ends with  s_waitcnt lgkmcnt(0) ; s_waitcnt vmcnt(N_j) ; s_barrier.
-// Write-after-read: every LDS read issued in phase P has completed at P's closing barrier (lgkmcnt(0)); a unit is restaged
-// only in a phase after the one that issued its last read (A-h1: last read issued in j=2 of the previous tile of that
-// buffer, restaged two phases later; B-k0: read in j=2 of tile t-1, restaged in j=1 of t; A-h0: j=1 -> j=2; B-k1: j=0 -> j=3).
-// Read-after-write: a wave's DMA has landed when its counted vmcnt wait says so, everybody's when all waves have passed the
-// barrier behind that wait; the first read of a unit is issued in a LATER phase than that barrier closes:
-//     unit          staged in       first read issued in   wait at the end of    DMAs issued since (may stay in flight)
-//     B-k0(t+1)     (t-1, j=1)      (t, j=2)               (t, j=1)              4 units -> vmcnt(8)
-//     A-h0(t+1)     (t-1, j=2)      (t, j=3)               (t, j=2)              4 units -> vmcnt(8)
-//     B-k1(t+1)     (t-1, j=3)      (t+1, j=0)             (t, j=3)              3 units -> vmcnt(6)
-//     A-h1(t+1)     (t,   j=0)      (t+1, j=0)             (t, j=3)              3 units -> vmcnt(6)
+// Schedule (ping-pong).  A K tile is four phases of 16 MFMAs per wave: (k block, row half) = (0,0) (0,1) (1,0) (1,1).  A
+// phase is  [reads of ITS fragments, stage one unit, s_waitcnt lgkmcnt(0), s_waitcnt vmcnt(N)] s_barrier [16 MFMAs] s_barrier;
+// waves 4..7 -- the second wave of every SIMD -- enter through one extra barrier (and waves 0..3 leave through one), so
+// every s_barrier pairs the end of one group's read section with the end of the other's MFMA section: while one wave of a
+// SIMD reads and issues its DMA, the other has the matrix core.  Reads come BEFORE the DMA issue: an LDS-DMA instruction
+// holds the wave's issue for 60..180 cycles (the CU's one address unit serves four waves at once), the fragments arrive
+// meanwhile.
+//   stage:  j=0: A-h1(t+1)   j=1: B-k0(t+2)   j=2: B-k1(t+1)   j=3: A-h0(t+2)
+// Write-after-read: the reads a group issues in phase Q have completed at that group's next barrier (lgkmcnt(0)), both
+// groups' two barriers after phase Q began; a unit last read in phase Q is restaged in phase Q + 1 at the earliest
+// (A-h0: read (t,0) (t,2) -> (t,3); A-h1: (t,1) (t,3) -> (t+1,0); B-k0: (t,0) -> (t,1); B-k1: (t,2) -> (t+1,2)).
+// Read-after-write: a wave's DMA has landed when its counted vmcnt wait says so, everybody's when both groups have passed
+// the barrier behind that wait -- waited for in the read section of phase W, first read in phase W + 1:
+//     unit          staged in     waited for in   first read in   DMAs issued since (may stay in flight)
+//     A-h1(t+1)     (t, j=0)      (t+1, j=0)      (t+1, j=1)      4 units -> vmcnt(8)
+//     B-k1(t+1)     (t, j=2)      (t+1, j=1)      (t+1, j=2)      3 units -> vmcnt(6)
+//     B-k0(t+2)     (t, j=1)      (t+1, j=3)      (t+2, j=0)      (in order: landed before A-h0(t+2))
+//     A-h0(t+2)     (t, j=3)      (t+1, j=3)      (t+2, j=0)      4 units -> vmcnt(8)
 // (vmcnt counts in order, and these DMAs are the loop's only vector-memory instructions.)  Past the last tile the stages
 // repeat the last tile's sources -- straight-line, the counts stay what the table says -- into units nobody reads again.
+// Measured and dropped (same tool, same box; the numbers are q|k|v / down): lockstep phases with the next phase's
+// fragments read one phase ahead and ONE barrier per phase 1.26 / 1.25 PFLOP/s; this ping-pong with the DMA issued in
+// front of the reads 1.29 / 1.30; the DMA issued at the head of the MFMA section 1.25 / 1.24; the units going round
+// rings of five slots (all 160 KiB, every unit staged a tile earlier: five to seven phases in flight) 1.26 / 1.27 -- the
+// copies' latency is covered with two buffers, what counts is the length of the read section; no s_setprio: the same.
 constexpr int DMA_BUF = 65536, DMA_UNIT = 16384;
 
 __device__ __forceinline__ void dma_kib(const void* gsrc, unsigned lds_dst) {
@@ -509,14 +520,7 @@ __device__ __forceinline__ void dma_kib(const void* gsrc, unsigned lds_dst) {
 }
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
 
-template <int VM>
-__device__ __forceinline__ void phase_close() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if constexpr (VM >= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM) : "memory");
-  asm volatile("s_barrier" ::: "memory");
-}
-
-template <typename AT, bool SWIGLU, int SCHED>
+template <typename AT, bool SWIGLU>
 __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) dst[nt] = *(const lds_u32x4_t*)(size_t)(b_lane + off + nt * 1024);
   };
-  // two K-tile buffers (SCHED 0 / 1): tile t in buffer t & 1 = [A-h0][A-h1][B-k0][B-k1]
+  // tile t in buffer t & 1 = [A-h0][A-h1][B-k0][B-k1]
   auto stage_a = [&](int t, int h) { stage_a_at(t, h, (t & 1) * DMA_BUF + h * DMA_UNIT); };
   auto stage_b = [&](int t, int kb) { stage_b_at(t, kb, (t & 1) * DMA_BUF + (2 + kb) * DMA_UNIT); };
   auto a_frags = [&](int t, int kb, int h, u32x4 (&dst)[4]) { a_frags_at((t & 1) * DMA_BUF + h * DMA_UNIT, kb, dst); };
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 af[2][4], bf[2][4];
+  u32x4 af[1][4], bf[2][4];
 
   auto mma = [&](int h, const u32x4 (&a)[4], const u32x4 (&b)[4]) {
 #pragma unroll
@@ -600,20 +604,8 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
       for (int nt = 0; nt < 4; ++nt) acc[h * 4 + mt][nt] = mfma16<AT>(a[mt], b[nt], acc[h * 4 + mt][nt]);
   };
 
-  if constexpr (SCHED == 1) {
-    // ---- ping-pong: the two waves of a SIMD (w and w + 4) run half a phase apart -- while one issues its DMA and reads the
-    // fragments of its phase, the other has the matrix core.  A phase is [stage, reads, waits] barrier [16 MFMAs] barrier;
-    // waves 4..7 enter through one extra barrier (and waves 0..3 leave through one), so every s_barrier pairs the end of one
-    // group's read section with the end of the other's MFMA section.  Reads are for the SAME phase (one fragment set).
-    //   stage:  j=0: A-h1(t+1)   j=1: B-k0(t+2)   j=2: B-k1(t+1)   j=3: A-h0(t+2)
-    // Write-after-read: a unit last read in phase Q (both groups' reads have completed two barriers later) is restaged in
-    // phase Q + 1 at the earliest (A-h0: read (t,0) (t,2) -> (t,3); A-h1: (t,1) (t,3) -> (t+1,0); B-k0: (t,0) -> (t,1);
-    // B-k1: (t,2) -> (t+1,2)).  Read-after-write: waited for in the read section of phase W, first read in phase W + 1:
-    //     unit          staged in     waited for in   first read in   DMAs issued since
-    //     A-h1(t+1)     (t, j=0)      (t+1, j=0)      (t+1, j=1)      4 units -> vmcnt(8)
-    //     B-k1(t+1)     (t, j=2)      (t+1, j=1)      (t+1, j=2)      3 units -> vmcnt(6)
-    //     B-k0(t+2)     (t, j=1)      (t+1, j=3)      (t+2, j=0)      (in order: landed before A-h0(t+2))
-    //     A-h0(t+2)     (t, j=3)      (t+1, j=3)      (t+2, j=0)      4 units -> vmcnt(8)
+  {
+    // prologue: tile 0 whole and what the phases of tiles -2 / -1 would have staged, in their order
     stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(1, 0); stage_b(0, 1); stage_a(1, 0);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -623,8 +615,6 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
       asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
 #define PP_MMA_DONE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); asm volatile("s_barrier" ::: "memory"); \
       __builtin_amdgcn_sched_barrier(0); } while (0)
-    // (reads before the DMA issue: an LDS-DMA instruction holds the wave's issue for 60..180 cycles -- the fragments arrive
-    // meanwhile, and the lgkmcnt(0) of the close finds them there)
 #define PP_ORDER() __builtin_amdgcn_sched_barrier(0)
     for (int t = 0; t < nk; ++t) {
       b_frags(t, 0, bf[0]); a_frags(t, 0, 0, af[0]); PP_ORDER(); stage_a(t + 1, 1);
@@ -648,88 +638,6 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
 #undef PP_READS_DONE
 #undef PP_MMA_DONE
     if (wave < 4) asm volatile("s_barrier" ::: "memory");
-  } else if constexpr (SCHED == 2) {
-    // ---- ping-pong over all 160 KiB of LDS: the A units of consecutive tiles go round a ring of FIVE 16-KiB slots (unit
-    // a = 2 t + h in slot a mod 5), the B units round another (b = 2 t + kb) -- 2.5 tiles of each operand instead of 2, and
-    // every unit is staged a whole tile earlier than with two tile buffers: five to seven phases in flight instead of three
-    // or four.  (With the DMA issue moved HALF a phase later the two-buffer form lost 6 %: the copies' latency is not fully
-    // covered there.)
-    //   stage (all of tile t + 2):  j=0: B-k0   j=1: A-h0   j=2: B-k1   j=3: A-h1
-    // Write-after-read (restage in phase Q + 1 at the earliest, Q = last phase that reads the slot's old unit):
-    //     B-k0(t+2) -> slot of B-k1(t-1), last read (t-1, 2)        A-h0(t+2) -> slot of A-h1(t-1), last read (t-1, 3)
-    //     B-k1(t+2) -> slot of B-k0(t),   last read (t, 0)          A-h1(t+2) -> slot of A-h0(t),   last read (t, 2): staged (t, 3)
-    // Read-after-write (waited for in the read section of phase W, first read in W + 1 or later):
-    //     unit          staged in     waited for in   first read in   DMAs issued since
-    //     B-k0(t+2)     (t, j=0)      (t+1, j=3)      (t+2, j=0)      (in order: landed before A-h0(t+2))
-    //     A-h0(t+2)     (t, j=1)      (t+1, j=3)      (t+2, j=0)      6 units -> vmcnt(12)
-    //     B-k1(t+2)     (t, j=2)      (t+2, j=0)      (t+2, j=2)      (in order: landed before A-h1(t+2))
-    //     A-h1(t+2)     (t, j=3)      (t+2, j=0)      (t+2, j=1)      5 units -> vmcnt(10)
-    constexpr unsigned RB = 5 * DMA_UNIT;                  // the B ring starts behind the A ring
-    auto slot = [&](int s5, int d) -> unsigned { const int v = s5 + d; return (unsigned)(v >= 10 ? v - 10 : v >= 5 ? v - 5 : v) * DMA_UNIT; };
-    // tiles 0 and 1 whole, in the order the phases of tiles -2 / -1 would have staged them (units a, b = 0..3 in slots 0..3)
-    stage_b_at(0, 0, RB + 0 * DMA_UNIT); stage_a_at(0, 0, 0 * DMA_UNIT); stage_b_at(0, 1, RB + 1 * DMA_UNIT); stage_a_at(0, 1, 1 * DMA_UNIT);
-    stage_b_at(1, 0, RB + 2 * DMA_UNIT); stage_a_at(1, 0, 2 * DMA_UNIT); stage_b_at(1, 1, RB + 3 * DMA_UNIT); stage_a_at(1, 1, 3 * DMA_UNIT);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    if (wave >= 4) asm volatile("s_barrier" ::: "memory");
-#define PP_READS_DONE(VM) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-      if (VM >= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM < 0 ? 0 : VM) : "memory"); \
-      asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
-#define PP_MMA_DONE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); asm volatile("s_barrier" ::: "memory"); \
-      __builtin_amdgcn_sched_barrier(0); } while (0)
-    int s5 = 0;                                            // (2 t) mod 5
-    for (int t = 0; t < nk; ++t) {
-      stage_b_at(t + 2, 0, RB + slot(s5, 4)); b_frags_at(RB + slot(s5, 0), bf[0]); a_frags_at(slot(s5, 0), 0, af[0]);
-      PP_READS_DONE(10);
-      mma(0, af[0], bf[0]);
-      PP_MMA_DONE();
-      stage_a_at(t + 2, 0, slot(s5, 4)); a_frags_at(slot(s5, 1), 0, af[0]);
-      PP_READS_DONE(-1);
-      mma(1, af[0], bf[0]);
-      PP_MMA_DONE();
-      stage_b_at(t + 2, 1, RB + slot(s5, 5)); b_frags_at(RB + slot(s5, 1), bf[1]); a_frags_at(slot(s5, 0), 1, af[0]);
-      PP_READS_DONE(-1);
-      mma(0, af[0], bf[1]);
-      PP_MMA_DONE();
-      stage_a_at(t + 2, 1, slot(s5, 5)); a_frags_at(slot(s5, 1), 1, af[0]);
-      PP_READS_DONE(12);
-      mma(1, af[0], bf[1]);
-      PP_MMA_DONE();
-      s5 = s5 + 2 >= 5 ? s5 - 3 : s5 + 2;
-    }
-#undef PP_READS_DONE
-#undef PP_MMA_DONE
-    if (wave < 4) asm volatile("s_barrier" ::: "memory");
-  } else {
-    // ---- prologue: tile 0 whole, then what the phases of tiles -2 / -1 would have staged, in their order
-    stage_b(0, 0); stage_a(0, 0); stage_b(0, 1); stage_a(0, 1);
-    stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    b_frags(0, 0, bf[0]);
-    a_frags(0, 0, 0, af[0]);
-
-    // The order inside a phase is pinned (sched_barrier): the DMA issue and the LDS reads for the NEXT phase first, then this
-    // phase's 16 MFMAs -- they only use registers that the previous phase loaded, so the reads complete in their shadow and
-    // the lgkmcnt(0) of the close costs nothing.  Left alone hipcc floats the MFMAs across the phase ends (they touch no
-    // memory) and sinks each read to just in front of its MFMA: four exposed LDS round trips per tile.
-    // (Measured and dropped: waves 4..7 running a phase as [stage, MFMAs, reads] so that the two waves of a SIMD take the
-    // matrix core in turn inside one barrier interval -- 10 % slower than this lockstep form; the ping-pong above, with its
-    // second barrier per phase, is what gains.)
-  #define PHASE(STAGE, READS, MMA, VM) do { \
-      __builtin_amdgcn_sched_barrier(0); \
-      STAGE; READS; \
-      __builtin_amdgcn_sched_barrier(0); \
-      MMA; \
-      __builtin_amdgcn_sched_barrier(0); \
-      phase_close<VM>(); } while (0)
-    for (int t = 0; t < nk; ++t) {
-      PHASE(stage_a(t + 1, 1), a_frags(t, 0, 1, af[1]); b_frags(t, 1, bf[1]), mma(0, af[0], bf[0]), -1);   // j = 0: (k0, h0)
-      PHASE(stage_b(t + 2, 0), a_frags(t, 1, 0, af[0]), mma(1, af[1], bf[0]), 8);                           // j = 1: (k0, h1)
-      PHASE(stage_a(t + 2, 0), a_frags(t, 1, 1, af[1]); b_frags(t + 1, 0, bf[0]), mma(0, af[0], bf[1]), 8); // j = 2: (k1, h0)
-      PHASE(stage_b(t + 2, 1), a_frags(t + 1, 0, 0, af[0]), mma(1, af[1], bf[1]), 6);                       // j = 3: (k1, h1)
-    }
-  #undef PHASE
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA of this workgroup may land after it has left the CU
 
@@ -1158,16 +1066,9 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     static const bool m32 = getenv("MI_GEMM_M32") != nullptr;               // A/B: the 32x32x16 form of the tile
     const char* dma_env = getenv("MI_GEMM_DMA");       // A/B and the bit-equality test: 0 = the register-staged tile (read per call)
     const bool dma = dma_env == nullptr || atoi(dma_env) != 0;
-    const int dma_sched = dma_env == nullptr ? 0 : std::max(0, atoi(dma_env) - 1);   // 1 = lockstep phases, 2.. = the ping-pong schedules
     const bool use_dma = dma && p.K >= 2 * BK;
 #define GO256(T, S) do { \
-      if (use_dma && dma_sched == 1) { auto k = gemm_dma256_kernel<T, S, 1>; \
-        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DMA_BUF)); \
-        hipLaunchKernelGGL(k, grid2, block2, 2 * DMA_BUF, st, p); } \
-      else if (use_dma && dma_sched == 2) { auto k = gemm_dma256_kernel<T, S, 2>; \
-        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * DMA_UNIT)); \
-        hipLaunchKernelGGL(k, grid2, block2, 10 * DMA_UNIT, st, p); } \
-      else if (use_dma) { auto k = gemm_dma256_kernel<T, S, 0>; \
+      if (use_dma) { auto k = gemm_dma256_kernel<T, S>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DMA_BUF)); \
         hipLaunchKernelGGL(k, grid2, block2, 2 * DMA_BUF, st, p); } \
       else if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \

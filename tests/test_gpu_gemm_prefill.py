@@ -17,7 +17,7 @@ from gpu_helpers import dev, gemm_prefill, host, op_linear, to_tiled  # noqa: E4
 from test_gpu_kernels import _assert_close  # noqa: E402
 
 RNG = np.random.default_rng(777)
-MODES = (1, 2, 3)      # MI_GEMM_DMA: 1 = lockstep phases, 2 = ping-pong, 3 = ping-pong over a ring of five units; 0 = the register-staged tile
+MODES = (1,)      # MI_GEMM_DMA: 1 = the LDS-DMA tile (default), 0 = the register-staged tile
 
 
 def _weight(kind, N, K):

@@ -49,6 +49,9 @@ EXACT_MARGIN, EXACT_LP, EXACT_LP_MEAN = 1e-2, 2e-2, 1e-3
 MODELKV_MARGIN, MODELKV_LP = 0.13, 0.1
 
 
+ULP_BITS = {"bfloat16": 7, "float16": 10, "float32": 23}      # mantissa bits: ulp(v) = 2 ** (floor(log2 |v|) - bits)
+
+
 def envelope_of(stem: str):
     """-> dict(max_lp, mean_lp, max_top8_lp, id_flips) = the larger of the two float32-accumulating variants' deviations
     from the exact oracle on this case, or None when the case has no committed envelope."""
@@ -135,7 +138,7 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
         margin_eps = min(margin_eps, max(ENVELOPE_FACTOR * env["flip_margin"], 3.0 * ENVELOPE_FACTOR * env["max_lp"]))
     y = prompts
     near, lp_err, top_err, decided, lp_sum, lp_n = 0, 0.0, 0.0, 0, 0.0, 0
-    drawn = []
+    drawn, lp_all = [], []
     for s in range(steps):
         sp = SampleArgs(temp=spec["temp"], top_p=spec["top_p"], uniforms=None if greedy else g["uniforms"][s],
                         top_logprobs=8)
@@ -158,6 +161,7 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
             if g["margins"][s, b] > margin_eps:
                 decided += 1
             lp_err = max(lp_err, abs(float(res["logprobs"][b]) - float(g["logprobs"][s, b])))
+            lp_all.append(abs(float(res["logprobs"][b]) - float(g["logprobs"][s, b])))
             lp_sum, lp_n = lp_sum + abs(float(res["logprobs"][b]) - float(g["logprobs"][s, b])), lp_n + 1
             if wt in ids8:
                 logz = float(vals8[list(ids8).index(wt)]) - float(g["logprobs"][s, b])
@@ -178,10 +182,22 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
         f = ENVELOPE_FACTOR
         # (one bound for the chosen token and the 8 largest: in the 16-bit mode a logprob error IS a one-ulp flip of a logit --
         # 0.031 below |logit| 8, 0.0625 above -- and which of a row's large logits flips is chance)
-        assert lp_err <= f * max(env["max_lp"], env["max_top8_lp"]), (path.stem, "max |logprob - exact|", lp_err, env)
+        # 16-bit mode: errors come in quanta -- one ulp of a 16-bit logit (top_vals are the oracle's logits), on top of a
+        # small drift of log Z -- and the envelope's maximum over a few hundred samples is one draw from that distribution's
+        # tail: the device may show ONE more one-ulp flip than the envelope's worst sample, and only in a handful of samples
+        # (the mean bound below is the statistically tight one)
+        E = max(env["max_lp"], env["max_top8_lp"])
+        quantum = 0.0 if exact else float(2.0 ** (np.floor(np.log2(np.abs(g["top_vals"]).max())) - ULP_BITS[cfg.get("torch_dtype", "bfloat16")]))
+        assert lp_err <= max(f * E, E + 1.05 * quantum), (path.stem, "max |logprob - exact|", lp_err, env, quantum)
+        # how many samples may lie beyond the envelope's worst: the CPU variants themselves show such two-quantum samples
+        # in 0.05 .. 0.5 % of a case's chosen tokens (5 of ~9000 over the nine 16-bit cases), and the device's float32 sums
+        # (matrix-core dot products of 32 terms + split-K partial sums) are not IEEE-sequential -- its MEAN error runs
+        # 0.97 .. 1.33 x the envelope's (bounded at 1.5 x below); 2 % caps the tail without making it a coin toss
+        over = int(np.sum(np.asarray(lp_all) > f * E))
+        assert over <= max(2, len(lp_all) // 50), (path.stem, "samples beyond the envelope", over, len(lp_all), env)
         assert lp_sum / max(lp_n, 1) <= f * env["mean_lp"], (path.stem, "mean |logprob - exact|", lp_sum / max(lp_n, 1), env)
         if greedy:
-            assert top_err <= f * max(env["max_top8_lp"], env["max_lp"]), (path.stem, "top-8 logprobs", top_err, env)
+            assert top_err <= max(f * E, E + 1.05 * quantum), (path.stem, "top-8 logprobs", top_err, env, quantum)
             # (every flip was checked against the envelope's flip margin where it happened; the count is bounded by how many
             # (step, row) pairs lie under that margin at all)
             assert near <= int((g["margins"] <= margin_eps).sum()), (path.stem, "greedy id flips", near, env)

@@ -20,12 +20,12 @@ for name, N, K, epi in shapes:
     no = N // 2 if epi == L.EPI_SWIGLU else N
     out = torch.zeros((M, no), dtype=torch.bfloat16, device="cuda")
     kw = dict(epi=epi, out=out, ldo=no, resid=out if epi == L.EPI_RESID else None, pair_offset=N // 2 if epi == L.EPI_SWIGLU else 0)
-    res = {k: [] for k in "0123"}
+    res = {k: [] for k in "01"}
     for r in range(rounds):
-        for v in "0123":
+        for v in "01":
             os.environ["MI_GEMM_DMA"] = v
             res[v].append(gemm_prefill(ol, x, M, "bfloat16", iters=10, **kw))
     fl = 2.0 * M * N * K
-    for v, lab in (("0", "register-staged"), ("1", "LDS-DMA"), ("2", "LDS-DMA ping-pong"), ("3", "pp, ring of five")):
+    for v, lab in (("0", "register-staged"), ("1", "LDS-DMA ping-pong")):
         ms = np.array(res[v])
         print(f"{name:8s} {lab:20s} median {np.median(ms)*1e3:8.1f} us  min {ms.min()*1e3:8.1f} us   {fl/np.median(ms)/1e9:7.1f} TFLOP/s (median)", flush=True)
