@@ -49,8 +49,10 @@ constexpr int KB = 32;      // keys per block
 
 // QG: query groups of 16 per wave (the launcher uses 1: see launch_pg).  With QG = 2 a workgroup covers 32 queries and every
 // K / V fragment a wave reads from LDS feeds two MFMAs.
+// (launch bounds: two waves per SIMD, i.e. up to 256 registers.  Left to itself hipcc aims at three, keeps the output
+// accumulators in AGPRs and moves them to VGPRs and back around every rescale: 88 v_accvgpr moves per block of 16 MFMAs.)
 template <typename T, int D, int G, bool PAGED, int QG>
-__global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
+__global__ __launch_bounds__(G * 64, 2) void attn_prefill_kernel(AttnCall c) {
   static_assert(sizeof(T) == 2 && D % 32 == 0 && D <= 128, "16-bit activations / caches, head_dim 32..128");
   constexpr int KK = D / 32, DT = D / 16, NT = G * 64;
   constexpr int QTT = QT * QG;                        // queries per workgroup
@@ -76,32 +78,36 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
   const T* kc = (const T*)c.kcache;
   const T* vc = (const T*)c.vcache;
 
-  u32x4 kreg[NP], vreg[NP];
-  auto load_block = [&](int j) {
+  // Two register sets: the loads of block j + 2 are issued at the head of iteration j and written to LDS at the end of
+  // iteration j + 1 -- two iterations (~2 x 600 cycles of work) to arrive.  With ONE block ahead an iteration lasted as
+  // long as an L2 / HBM round trip (3.3 us per workgroup and block at three workgroups per CU, stamps of the bench shape).
+  u32x4 kreg[2][NP], vreg[2][NP];
+  auto load_block = [&](int j, u32x4 (&kr)[NP], u32x4 (&vr)[NP]) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int piece = min(i * NT + tid, NPIECE - 1);
       const int key = min(j * KB + piece / (D / 8), nk - 1), dc = piece % (D / 8);
       const size_t ro = kv_elem<PAGED>(s, kb, kh, key) + 8 * dc;
-      kreg[i] = *(const u32x4*)(kc + ro);
-      vreg[i] = *(const u32x4*)(vc + ro);
+      kr[i] = *(const u32x4*)(kc + ro);
+      vr[i] = *(const u32x4*)(vc + ro);
     }
   };
-  auto store_block = [&](int buf) {
+  auto store_block = [&](int buf, const u32x4 (&kr)[NP], const u32x4 (&vr)[NP]) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int piece = i * NT + tid;
       if (piece < NPIECE) {
         const int key = piece / (D / 8), dc = piece % (D / 8);
         // K: [16-key tile][kk][g][key & 15] x 16 B -- a fragment read of (tile, kk) is 1 KiB contiguous
-        *(u32x4*)(kimg[buf] + ((((key >> 4) * KK + (dc >> 2)) * 4 + (dc & 3)) * 16 + (key & 15)) * 16) = kreg[i];
+        *(u32x4*)(kimg[buf] + ((((key >> 4) * KK + (dc >> 2)) * 4 + (dc & 3)) * 16 + (key & 15)) * 16) = kr[i];
         // V: [16-d tile][key][16 d] (32-byte rows) for the transposed reads
-        *(u32x4*)(vimg[buf] + (size_t)(dc >> 1) * (KB * 32) + key * 32 + (dc & 1) * 16) = vreg[i];
+        *(u32x4*)(vimg[buf] + (size_t)(dc >> 1) * (KB * 32) + key * 32 + (dc & 1) * 16) = vr[i];
       }
     }
   };
 
-  load_block(0);
+  load_block(0, kreg[0], vreg[0]);
+  load_block(1, kreg[1], vreg[1]);                    // (past the last block: clamped keys, never stored)
   // Q^T fragments of this wave's head (B operand: column = query), one set per query group
   u32x4 qf[QG][KK];
   int tq[QG];
@@ -112,7 +118,14 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) qf[u][kk] = *(const u32x4*)(qp + 32 * kk + 8 * g4);
   }
-  store_block(0);
+  store_block(0, kreg[0], vreg[0]);
+  // The Q fragments count as loaded from HERE on.  Without this "use" hipcc's wait-count pass carries their pending loads
+  // round the loop's back edge and puts s_waitcnt vmcnt(0) in front of the first MFMAs of EVERY iteration -- which drains
+  // the K / V loads just issued for two blocks ahead: one exposed memory round trip per block (290 -> 1xx us per layer).
+#pragma unroll
+  for (int u = 0; u < QG; ++u)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" :: "v"(qf[u][kk]));
   __syncthreads();
 
   const float sc2 = c.scale * LOG2E;
@@ -126,9 +139,10 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
   }
   const int tq4 = c16 >> 2, tp = c16 & 3;
 
-  for (int j = 0; j < nb; ++j) {
+  // iteration j: kfree / vfree = the set block j was stored from (free), knext / vnext = the set holding block j + 1
+  auto iter = [&](int j, u32x4 (&kfree)[NP], u32x4 (&vfree)[NP], const u32x4 (&knext)[NP], const u32x4 (&vnext)[NP]) {
     const int buf = j & 1;
-    if (j + 1 < nb) load_block(j + 1);                // uniform branch; the loads fly during this block's MFMAs
+    load_block(j + 2, kfree, vfree);                  // straight-line (past the last block: clamped keys, never stored); these loads fly during two blocks' work
     f32x4 sc[QG][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -191,9 +205,207 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_kernel(AttnCall c) {
 #pragma unroll
       for (int u = 0; u < QG; ++u) accO[u][dt] = mfma16<T>(vf, pf[u], accO[u][dt]);
     }
-    if (j + 1 < nb) store_block(buf ^ 1);             // the other buffer: nobody reads it during this block
+    if (j + 1 < nb) store_block(buf ^ 1, knext, vnext);   // the other buffer: nobody reads it during this block
     __syncthreads();
+  };
+  for (int j = 0; j < nb; j += 2) {
+    iter(j, kreg[0], vreg[0], kreg[1], vreg[1]);
+    if (j + 1 < nb) iter(j + 1, kreg[1], vreg[1], kreg[0], vreg[0]);
   }
+
+#pragma unroll
+  for (int u = 0; u < QG; ++u) {
+    float l = l_run[u];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (t0 + QT * u + c16 < s.L) {
+      const float inv = 1.0f / l;
+      T* op = (T*)c.out + ((size_t)b * s.L + tq[u]) * s.Hq * D + (size_t)h * D + 4 * g4;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const u32x2 v = {pack2<T>(accO[u][dt][0] * inv, accO[u][dt][1] * inv), pack2<T>(accO[u][dt][2] * inv, accO[u][dt][3] * inv)};
+        *(u32x2*)(op + 16 * dt) = v;
+      }
+    }
+  }
+}
+
+// one KiB: global (per-lane source address) -> LDS at a wave-uniform address (lane-linear)
+__device__ __forceinline__ void dma_kib(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// (launch bounds: two waves per SIMD, i.e. up to 256 registers.  Left to itself hipcc aims at three, keeps the output
+// accumulators in AGPRs and moves them to VGPRs and back around every rescale: 88 v_accvgpr moves per block of 16 MFMAs.)
+template <typename T, int D, int G, bool PAGED, int QG>
+__global__ __launch_bounds__(G * 64, G >= 2 ? 2 : 1) void attn_prefill_dma_kernel(AttnCall c) {
+  static_assert(sizeof(T) == 2 && D % 32 == 0 && D <= 128, "16-bit activations / caches, head_dim 32..128");
+  constexpr int KK = D / 32, DT = D / 16, NT = G * 64;
+  constexpr int QTT = QT * QG;                        // queries per workgroup
+  constexpr int NPIECE = KB * D / 8;                  // 16-byte pieces of one K (or V) block
+  constexpr int NP = (NPIECE + NT - 1) / NT;          // per thread
+  constexpr int IMG = KB * D * 2;                     // bytes of one image
+  constexpr float LOG2E = 1.4426950408889634f;
+  const AttnShape& s = c.s;
+  const int qt = gridDim.x - 1 - blockIdx.x, bh = blockIdx.y;
+  const int b = bh / s.Hkv, kh = bh % s.Hkv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = s.rows ? s.rows[b] : b;              // cache row of batch entry b
+  const int off = c.offsets[kb];
+  const int t0 = qt * QTT;
+  const int nk = off + min(t0 + QTT, s.L);            // keys any query of the tile may see
+  const int nb = (nk + KB - 1) / KB;
+  const int h = kh * G + wave;
+
+  // K / V blocks go global -> LDS by LDS-DMA into a ring of THREE buffers: block j + 2 is issued at the head of
+  // iteration j (into the buffer block j - 1 was read from: every wave finished those reads before the barrier that
+  // closed iteration j - 1) and waited for at the end of iteration j + 1 (s_waitcnt vmcnt(that block's DMAs of this
+  // wave), then the barrier: the block is everybody's).  No staging registers, no ds_write -- and no compiler-visible
+  // vector loads in the loop: with K / V loaded into registers hipcc's wait-count pass put s_waitcnt vmcnt(0) at the head
+  // of the loop body (a register-reuse hazard it could not rule out across the back edge), which drained the prefetch
+  // just issued and exposed a memory round trip every block: 268 us per layer at 8 x 1024 tokens against 191 here.
+  // The images are those of attn_prefill_kernel; a DMA writes lane-linear, so the layout is realised through each
+  // lane's SOURCE address: K instruction i covers slots 64 i .. 64 i + 63 of [16-key tile][kk][g][key & 15], V
+  // instruction i the 32 keys x 32 bytes of 16-d tile i.
+  constexpr int NINST = NPIECE / 64;                  // DMA instructions per image and block
+  constexpr int CNT = (NINST + G - 1) / G;            // per wave (the last wave may repeat the last instruction: same bytes, same place)
+  __shared__ __attribute__((aligned(16))) unsigned char kimg[3][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char vimg[3][IMG];
+  const unsigned k_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&kimg[0][0];
+  const unsigned v_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&vimg[0][0];
+
+  const T* kc = (const T*)c.kcache;
+  const T* vc = (const T*)c.vcache;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_block = [&](int j, int buf) {
+#pragma unroll
+    for (int n = 0; n < CNT; ++n) {
+      const int i = min(wv + G * n, NINST - 1);
+      {   // K: slot S = 64 i + lane = (((kt * KK + kk) * 4 + dclo) * 16 + klo)
+        const int S = i * 64 + lane;
+        const int klo = S & 15, dclo = (S >> 4) & 3, tk = S >> 6, kk = tk % KK, kt = tk / KK;
+        const int key = min(j * KB + kt * 16 + klo, nk - 1);
+        const T* src = kc + kv_elem<PAGED>(s, kb, kh, key) + 8 * (kk * 4 + dclo);
+        dma_kib(src, k_lds + buf * IMG + i * 1024);
+      }
+      {   // V: slot S = dt * 64 + key * 2 + (dc & 1)
+        const int key = min(j * KB + (lane >> 1), nk - 1);
+        const T* src = vc + kv_elem<PAGED>(s, kb, kh, key) + 8 * (i * 2 + (lane & 1));
+        dma_kib(src, v_lds + buf * IMG + i * 1024);
+      }
+    }
+  };
+
+  // Q^T fragments of this wave's head (B operand: column = query), one set per query group
+  u32x4 qf[QG][KK];
+  int tq[QG];
+#pragma unroll
+  for (int u = 0; u < QG; ++u) {
+    tq[u] = min(t0 + QT * u + c16, s.L - 1);          // this lane's query of group u (clamped; stores are guarded)
+    const T* qp = (const T*)c.q + ((size_t)b * s.L + tq[u]) * s.Hq * D + (size_t)h * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[u][kk] = *(const u32x4*)(qp + 32 * kk + 8 * g4);
+  }
+  dma_block(0, 0);
+  dma_block(1, 1);                                    // (past the last block: clamped keys, masked)
+  // the Q fragments count as loaded from here on (hipcc waits for its own loads with vmcnt(0): blocks 0 and 1 have landed too)
+#pragma unroll
+  for (int u = 0; u < QG; ++u)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" :: "v"(qf[u][kk]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sc2 = c.scale * LOG2E;
+  float m_run[QG], l_run[QG];
+  f32x4 accO[QG][DT];
+#pragma unroll
+  for (int u = 0; u < QG; ++u) {
+    m_run[u] = -1e30f; l_run[u] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) accO[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int tq4 = c16 >> 2, tp = c16 & 3;
+
+  int buf = 0;                                        // j mod 3
+  for (int j = 0; j < nb; ++j) {
+    const int bnext2 = buf == 0 ? 2 : buf - 1;        // (j + 2) mod 3
+    dma_block(j + 2, bnext2);
+    f32x4 sc[QG][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int u = 0; u < QG; ++u) sc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const u32x4 kf = *(const u32x4*)(kimg[buf] + (((t * KK + kk) * 4 + g4) * 16 + c16) * 16);
+#pragma unroll
+        for (int u = 0; u < QG; ++u) sc[u][t] = mfma16<T>(kf, qf[u][kk], sc[u][t]);
+      }
+    }
+    u32x4 pf[QG];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+      // The vector ALU, not the matrix core, bounds this loop (~110 vector instructions + 9 transcendentals per 16 MFMAs
+      // as first written), so: the causal mask only in the blocks that reach past the group's first query (uniform), the
+      // scale folded into the exponent's FMA, and O / l rescaled only when some query's running max moved (uniform;
+      // multiplying by exp2(0) = 1 is the identity, so skipping it changes no bit).
+      const int qpos = off + t0 + QT * u + c16;       // key positions <= qpos are visible to this lane's query of group u
+      float mx = -INFINITY;
+      if (j * KB + KB - 1 > off + t0 + QT * u) {      // a diagonal block of this group
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (j * KB + 16 * t + 4 * g4 + r) <= qpos;
+            sc[u][t][r] = ok ? sc[u][t][r] : -INFINITY;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[u][t][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m_run[u], mx * sc2);     // (scale > 0: the largest raw score is the largest scaled one)
+      if (__builtin_amdgcn_ballot_w64(mn != m_run[u]) != 0) {
+        const float corr = __builtin_amdgcn_exp2f(m_run[u] - mn);
+        m_run[u] = mn;
+        l_run[u] *= corr;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) accO[u][dt] *= corr;
+      }
+      float p[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[u][t][r], sc2, -mn)); l_run[u] += p[t][r]; }
+      pf[u] = u32x4{pack2<T>(p[0][0], p[0][1]), pack2<T>(p[0][2], p[0][3]), pack2<T>(p[1][0], p[1][1]), pack2<T>(p[1][2], p[1][3])};
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const unsigned char* a0 = vimg[buf] + (size_t)dt * (KB * 32) + (4 * g4 + tq4) * 32 + tp * 8;
+      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 32));
+      const uint32_t* w0 = (const uint32_t*)&v0;
+      const uint32_t* w1 = (const uint32_t*)&v1;
+      const u32x4 vf = {w0[0], w0[1], w1[0], w1[1]};
+#pragma unroll
+      for (int u = 0; u < QG; ++u) accO[u][dt] = mfma16<T>(vf, pf[u], accO[u][dt]);
+    }
+    // lgkmcnt(0): every LDS read of this iteration has RETURNED before the barrier lets another wave issue the DMA that
+    // overwrites this buffer's predecessor -- hipcc may sink an MFMA, and the wait in front of it, below the barrier, and
+    // under load (four workgroups per CU on the LDS queue) a read issued just before the barrier was still queued when a
+    // fast wave's DMA landed: wrong tiles that came and went with the load on the chip (tests/test_gpu_fullsize.py).
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * CNT) : "memory");    // and block j + 1 has landed (block j + 2 may still fly)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA of this workgroup may land after it has left the CU
 
 #pragma unroll
   for (int u = 0; u < QG; ++u) {
@@ -219,8 +431,14 @@ int launch_pg(const AttnCall& c, hipStream_t st) {
   // measured: prefill 83.3 .. 83.8 k tok/s against 84.0 .. 84.1 k (same box, alternating runs) -- the vector ALU bounds the
   // loop, not the LDS traffic -- and 79 k once the leaner softmax below pushed it past 256 registers.
   const dim3 grid((s.L + QT - 1) / QT, s.B * s.Hkv), block(G * 64);
-  if (s.btab) hipLaunchKernelGGL((attn_prefill_kernel<T, D, G, true, 1>), grid, block, 0, st, c);
-  else hipLaunchKernelGGL((attn_prefill_kernel<T, D, G, false, 1>), grid, block, 0, st, c);
+  const char* env = getenv("MI_ATTN_PREFILL_DMA");     // A/B and the bit-equality test: 0 = the register-staged kernel (read per call)
+  if (env == nullptr || atoi(env) != 0) {
+    if (s.btab) hipLaunchKernelGGL((attn_prefill_dma_kernel<T, D, G, true, 1>), grid, block, 0, st, c);
+    else hipLaunchKernelGGL((attn_prefill_dma_kernel<T, D, G, false, 1>), grid, block, 0, st, c);
+  } else {
+    if (s.btab) hipLaunchKernelGGL((attn_prefill_kernel<T, D, G, true, 1>), grid, block, 0, st, c);
+    else hipLaunchKernelGGL((attn_prefill_kernel<T, D, G, false, 1>), grid, block, 0, st, c);
+  }
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -262,7 +480,7 @@ int launch_pt(const AttnCall& c, hipStream_t st) {
 constexpr int KB32 = 16;    // keys per block, float32 kernel
 
 template <int D, int G, bool PAGED>
-__global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
+__global__ __launch_bounds__(G * 64, 2) void attn_prefill_f32_kernel(AttnCall c) {
   static_assert(D % 64 == 0 && D <= 128, "float32: head_dim 64 / 128");
   constexpr int NP = D / 16, NH = D / 64, DT = D / 16, NT = G * 64;
   constexpr int NPIECE = KB32 * D / 4;                // 16-byte pieces of one K (or V) block
@@ -319,6 +537,8 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
     for (int i = 0; i < NP; ++i) qf[i] = *(const f32x4*)(qp + 16 * i + 4 * g4);
   }
   store_block(0);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) asm volatile("" :: "v"(qf[i]));     // (see attn_prefill_kernel: the Q loads are complete from here on)
   __syncthreads();
 
   const float sc2 = c.scale * LOG2E;
@@ -330,7 +550,7 @@ __global__ __launch_bounds__(G * 64) void attn_prefill_f32_kernel(AttnCall c) {
 
   for (int j = 0; j < nb; ++j) {
     const int buf = j & 1;
-    if (j + 1 < nb) load_block(j + 1);                // uniform branch; the loads fly during this block's MFMAs
+    load_block(j + 1);                                // straight-line (past the last block: clamped keys, never stored); the loads fly during this block's MFMAs
     f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NP; ++i) {

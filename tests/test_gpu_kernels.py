@@ -8,6 +8,8 @@ boundary; we require >= 99 % of elements within 2 ulp AND every element within 4
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -264,6 +266,52 @@ def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
             assert np.allclose(got, want, rtol=1e-4, atol=2e-5), np.abs(got - want).max()
         else:
             assert close_frac(got, want, act, atol=1e-3) <= 0.02, close_frac(got, want, act, atol=1e-3)
+        if L_ > 1 and act != "float32" and D >= 32:
+            # the LDS-DMA kernel (default) against the register-staged one it replaced: same images, same MFMA order
+            out0 = torch.zeros_like(out)
+            os.environ["MI_ATTN_PREFILL_DMA"] = "0"
+            try:
+                L.check(L.lib().mi_op_attention(C.byref(s), ptr(q_d), ptr(kc_d), ptr(vc_d), ptr(off_d), ptr(out0),
+                                                float(D ** -0.5), nsplit, ptr(part)))
+                torch.cuda.synchronize()
+            finally:
+                del os.environ["MI_ATTN_PREFILL_DMA"]
+            assert torch.equal(out, out0), "LDS-DMA prefill attention differs from the register-staged kernel"
+
+
+@pytest.mark.parametrize("act", ["bfloat16", "float16"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64), (5, 1, 32), (8, 1, 128)])
+def test_prefill_attention_many_blocks(act, Hq, Hkv, D):
+    """Prefill attention over several hundred keys (the K / V ring of three buffers goes round many times), ragged offsets,
+    against the oracle on sampled queries and bit for bit against the register-staged kernel."""
+    B, L_, cap = 3, 150, 512
+    offs = [0, 333, 97]
+    rng = np.random.default_rng(4242)        # (its own stream: the module's RNG feeds the tests below in file order)
+    kc = round_to(rng.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
+    vc = round_to(rng.standard_normal((B, Hkv, cap, D)).astype(np.float32), act)
+    q = round_to(rng.standard_normal((B, L_, Hq, D)).astype(np.float32), act)
+    s = attn_shape(B, L_, Hq, Hkv, D, act, act, 0, cap)
+    q_d, kc_d, vc_d, off_d = dev(q.reshape(B * L_, Hq * D), act), dev(kc, act), dev(vc, act), dev_i32(offs)
+    part = torch.zeros((16,), dtype=torch.float32, device="cuda")
+    outs = {}
+    for mode in ("1", "0"):
+        out = torch.zeros((B * L_, Hq * D), dtype=q_d.dtype, device="cuda")
+        os.environ["MI_ATTN_PREFILL_DMA"] = mode
+        try:
+            torch.cuda.synchronize()
+            L.check(L.lib().mi_op_attention(C.byref(s), ptr(q_d), ptr(kc_d), ptr(vc_d), ptr(off_d), ptr(out),
+                                            float(D ** -0.5), 1, ptr(part)))
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["MI_ATTN_PREFILL_DMA"]
+        outs[mode] = out
+    assert torch.equal(outs["1"], outs["0"]), "LDS-DMA prefill attention differs from the register-staged kernel"
+    got = host(outs["1"]).reshape(B, L_, Hq, D)
+    for b in range(B):
+        for t in (0, 1, 15, 16, 31, 32, 77, L_ - 1):
+            n = offs[b] + t + 1
+            o, _ = ref_model.sdpa(q[b:b + 1, t:t + 1].transpose(0, 2, 1, 3), kc[b:b + 1, :, :n], vc[b:b + 1, :, :n], D ** -0.5, None, act, act)
+            assert close_frac(got[b, t], o[0, :, 0], act, atol=1e-3) <= 0.02, (b, t)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -387,7 +435,9 @@ def test_sampler_top_p_injected_uniforms(V, temp, top_p):
             ids, cum = np.asarray(ids), np.cumsum(np.asarray(pr, dtype=np.float64) / np.sum(pr))
             rw, rg = int(np.where(ids == want["tokens"][b, 0])[0][0]), int(np.where(ids == toks[b])[0][0])
             edge = cum[min(rw, rg)]
-            assert abs(rw - rg) == 1 and abs(float(u[b]) - edge) <= 2e-6, (b, rw, rg, float(u[b]), edge)
+            # (the exponent's argument (x - max) / T * log2(e) reaches ~16 in float32: one rounding there is 1e-6 of a
+            # mass, and every mass below the edge carries a few of them -- seen: 3.2e-6 at a cumulative 0.70)
+            assert abs(rw - rg) == 1 and abs(float(u[b]) - edge) <= 8e-6, (b, rw, rg, float(u[b]), edge)
             mism += 1
     assert mism <= 1, (toks, want["tokens"][:, 0])
     assert np.allclose(lp, want["log_softmax"][np.arange(B), toks], atol=1e-4)
