@@ -490,11 +490,11 @@ int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, Gemv
       }
       scratch = e->deq_scratch;
     }
-    if (rows < 2048 && e->gk_ws == nullptr) {     // K-split partial tiles of the 128 x 128 GEMM (prompts of a few hundred rows)
+    if (rows < 4096 && e->gk_ws == nullptr) {     // K-split partial tiles of the tile GEMMs (one prompt of a few hundred to a few thousand rows)
       e->gk_cap = (size_t)128 << 20;
       if (hipMalloc(&e->gk_ws, e->gk_cap) != hipSuccess) { e->gk_ws = nullptr; e->gk_cap = 0; }
     }
-    MI_TRY(launch_gemm_prefill(f.W, c, rows, e->stream, scratch, rows < 2048 ? e->gk_ws : nullptr, e->gk_cap));
+    MI_TRY(launch_gemm_prefill(f.W, c, rows, e->stream, scratch, rows < 4096 ? e->gk_ws : nullptr, e->gk_cap));
     if (f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr) {   // y = T(y + T(scale (x A) B)) on the adapted columns
       GemvCall cl = c.act == MI_F32 ? c_in : c;
       cl.M = (int)rows;

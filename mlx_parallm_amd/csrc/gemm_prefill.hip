@@ -23,6 +23,8 @@
 
 namespace mi {
 
+int gemv_cu_count();      // gemv_mfma.hip
+
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -566,7 +568,12 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
   const int c16 = lane & 15, g = lane >> 4;
   const int bm = blockIdx.x, bn = blockIdx.y;
   const int m0 = bm * BM2;
-  const int nk = p.K / BK, nkw = p.kw / BK;
+  // K split over gridDim.z workgroups (a prompt of 256..4095 rows against N = 4096: the (M, N) grid alone leaves most CUs
+  // idle): slice z multiplies the K tiles [tb, tb + nk) and leaves its float32 partial tile in ws[z][M][N];
+  // splitk_epilogue_kernel adds the slices in order and applies the epilogue (host: >= 2 tiles per slice)
+  const int nk_all = p.K / BK, nkw = p.kw / BK;
+  const int tb = (int)(((long)blockIdx.z * nk_all) / gridDim.z);
+  const int nk = (int)(((long)(blockIdx.z + 1) * nk_all) / gridDim.z) - tb;
   const int ntiles_w = p.N / 16;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem2;
 
@@ -597,14 +604,14 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
 
   // unit A-h / B-kb of tile t (sources past the last tile repeat it) -> the 16 KiB at LDS byte offset `off`
   auto stage_a_at = [&](int t, int h, unsigned off) {
-    const int ts = min(t, nk - 1);
+    const int ts = tb + min(t, nk - 1);
     const size_t koff = (size_t)((ts * BK) % p.ka) * sizeof(AT);
     const unsigned dst = lds0 + off + wave * 2048;
     dma_kib(asrc[h][0] + koff, dst);
     dma_kib(asrc[h][1] + koff, dst + 1024);
   };
   auto stage_b_at = [&](int t, int kb, unsigned off) {
-    const int ts = min(t, nk - 1);
+    const int ts = tb + min(t, nk - 1);
     const size_t koff = (size_t)((ts % nkw) * 2 + kb) * 1024;
     const unsigned dst = lds0 + off + wave * 2048;
     dma_kib(bsrc[0] + koff, dst);
@@ -679,6 +686,24 @@ __global__ __launch_bounds__(512) void gemm_dma256_kernel(GemmParams p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA of this workgroup may land after it has left the CU
 
+  if constexpr (!SWIGLU) {
+    if (gridDim.z > 1) {                                   // this slice's partial tile, float32
+      float* wz = p.ws + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 128 + mt * 16 + 4 * g + r;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int n = bn * BN2 + wn * 64 + nt * 16 + c16;
+            if (n < p.N) wz[(size_t)m * p.N + n] = acc[mt][nt][r];
+          }
+        }
+      return;
+    }
+  }
   if constexpr (!SWIGLU) {
     if (p.epi == EPI_RESID) {
       if (p.out32) tile256_epilogue_resid<AT, float>(p, acc, m0, bn, wm, wn, c16, g);
@@ -1105,12 +1130,32 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
   // of 256..1024 tokens gives N/256 x (1..4) blocks -- 16..64 for N = 4096 -- and measured 25 / 25 / 30 ms for 256 / 512 /
   // 1024 tokens against 14 / 17 / 23 ms on the 128 x 128 tile (Mistral-7B bf16; tools/debug/prefill_sweep.py).
   const long blocks256 = (long)(((int)rows + BM2 - 1) / BM2) * ((ncols + (sw ? 128 : BN2) - 1) / (sw ? 128 : BN2));
-  if (rows >= 256 && !small_only && blocks256 >= 192) {  // both operands through LDS (gemm_tile256_kernel)
+  const char* dma_env = getenv("MI_GEMM_DMA");         // A/B and the bit-equality test: 0 = the register-staged tile (read per call)
+  const bool dma = dma_env == nullptr || atoi(dma_env) != 0;
+  // too few 256 x 256 tiles for the chip (one prompt of 256..4095 rows against N = 4096 / 6144): the LDS-DMA tile with K
+  // split over up to 8 workgroups, each >= 8 K tiles (plain / residual epilogues; SwiGLU launches have enough tiles or
+  // stay on the 128 x 128 kernel).  MI_GEMM_DMA_SPLITK=0 switches it off (A/B).
+  int ks256 = 1;
+  const char* sk_env = getenv("MI_GEMM_DMA_SPLITK");     // (read per call: the tests switch it)
+  const bool splitk256 = sk_env == nullptr || atoi(sk_env) != 0;
+  if (rows >= 256 && !small_only && dma && splitk256 && !sw && splitk_ws != nullptr && W.N % 4 == 0) {
+    // one 128-KiB workgroup per CU: the launch runs in rounds of n_cu workgroups.  Pick the split whose last round is
+    // fullest, charging 2 % per extra slice for its partial tile and its share of the reduce (q|k|v at 1024 rows: 96
+    // tiles -> 5 slices = 480 workgroups, 1.9 rounds; o_proj: 64 tiles -> 4 slices = one full round)
+    const int ncu = gemv_cu_count();
+    double best = 0.0;
+    for (int ks = 1; ks <= 8; ++ks) {
+      if (ks > 1 && ((p.K / BK) / ks < 8 || (size_t)ks * rows * W.N * sizeof(float) > splitk_cap)) break;
+      const long wgs = blocks256 * ks, rounds = (wgs + ncu - 1) / ncu;
+      const double score = (double)wgs / (double)(rounds * ncu) * (1.0 - 0.02 * (ks - 1));
+      if (score > best + 1e-9) { best = score; ks256 = ks; }
+    }
+  }
+  if (rows >= 256 && !small_only && (blocks256 >= 192 || ks256 > 1)) {  // both operands through LDS (256 x 256 tile)
     const int bn = sw ? 128 : BN2;
-    const dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
+    dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
+    if (ks256 > 1) { grid2.z = ks256; p.ksplit = ks256; p.ws = (float*)splitk_ws; }
     static const bool m32 = getenv("MI_GEMM_M32") != nullptr;               // A/B: the 32x32x16 form of the tile
-    const char* dma_env = getenv("MI_GEMM_DMA");       // A/B and the bit-equality test: 0 = the register-staged tile (read per call)
-    const bool dma = dma_env == nullptr || atoi(dma_env) != 0;
     const bool use_dma = dma && p.K >= 2 * BK;
 #define GO256(T, S) do { \
       if (use_dma) { auto k = gemm_dma256_kernel<T, S>; \
@@ -1129,6 +1174,13 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     else { if (sw) GO256(f16, true); else GO256(f16, false); }
 #undef GO256
     MI_HIP(hipGetLastError());
+    if (p.ksplit > 1) {
+      const size_t total4 = rows * (size_t)W.N / 4;
+      const dim3 rg((unsigned)((total4 + 255) / 256));
+      if (c.act == MI_F16) hipLaunchKernelGGL(splitk_epilogue_kernel<f16>, rg, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(splitk_epilogue_kernel<bf16>, rg, dim3(256), 0, st, p);
+      MI_HIP(hipGetLastError());
+    }
     return MI_OK;
   }
   dim3 grid(((int)rows + BM - 1) / BM, (ncols + (sw ? 64 : BN) - 1) / (sw ? 64 : BN)), block(256);

@@ -117,12 +117,15 @@ int mi_op_gemm_prefill(const mi_op_linear* w, const mi_op_gemv_args* a, int iter
   const GemvCall c = to_call(a);
   if (c.M < 1 || c.pro != PRO_NONE || W.layout != 1 || wk_is_quant(W.wk) || c.act == MI_F32)
     return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_prefill: tile-major dense 16-bit weights, 16-bit activations, no prologue");
-  int rc = launch_gemm_prefill(W, c, (size_t)c.M, nullptr, nullptr, nullptr, 0);
+  // K-split workspace as the engine holds it (float32 partial tiles; prompts below 4096 rows)
+  void* ws = nullptr; size_t cap = 0;
+  if (c.M < 4096) { cap = (size_t)128 << 20; MI_HIP(hipMalloc(&ws, cap)); }
+  int rc = launch_gemm_prefill(W, c, (size_t)c.M, nullptr, nullptr, ws, cap);
   if (rc == MI_OK && iters >= 1 && avg_ms) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && rc == MI_OK; ++i) rc = launch_gemm_prefill(W, c, (size_t)c.M, nullptr, nullptr, nullptr, 0);
+    for (int i = 0; i < iters && rc == MI_OK; ++i) rc = launch_gemm_prefill(W, c, (size_t)c.M, nullptr, nullptr, ws, cap);
     hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -131,6 +134,7 @@ int mi_op_gemm_prefill(const mi_op_linear* w, const mi_op_gemv_args* a, int iter
     hipEventDestroy(e0); hipEventDestroy(e1);
   }
   const int rc2 = finish();
+  if (ws) hipFree(ws);
   return rc != MI_OK ? rc : rc2;
 }
 

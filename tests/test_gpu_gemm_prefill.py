@@ -106,3 +106,40 @@ def test_swiglu_matches_oracle_and_the_register_staged_tile(act, kind, M, I, K):
     _assert_close(got[1][rows], want, act, scale=float(np.abs(y).max()))
     for m in MODES:
         assert np.array_equal(got[m], got[0]), f"LDS-DMA tile (MI_GEMM_DMA={m}) differs from the register-staged tile"
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "bf16"), ("float16", "f16")])
+@pytest.mark.parametrize("M,N,K", [
+    (1024, 4096, 4096),      # 4 x 16 tiles -> K split 4 ways, 16 K tiles per slice
+    (300, 2048, 2048),       # 2 x 8 tiles, ragged rows -> 4 slices of 8 K tiles
+    (2085, 4096, 1536),      # 9 x 16 tiles -> 2 slices of 12 K tiles
+])
+def test_k_split_of_the_lds_dma_tile(act, kind, M, N, K):
+    """One prompt of a few hundred rows: too few 256 x 256 tiles for the chip, so K is split over workgroups (float32
+    partial tiles + the ordered reduce).  Against the oracle on sampled rows; deterministic; the residual epilogue too."""
+    ol, w, keep = _weight(kind, N, K)
+    x = round_to(RNG.standard_normal((M, K)).astype(np.float32), act)
+    h0 = round_to(RNG.standard_normal((M, N)).astype(np.float32), act)
+    xd = dev(x, act)
+    rows = _rows(M)
+    y = round_to(matmul_nt(x[rows], w), act)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M + 3, N), 7.0, dtype=xd.dtype, device="cuda")
+        _run(ol, xd, M, act, 1, epi=L.EPI_STORE, out=out, ldo=N)
+        o = host(out)
+        assert np.all(o[M:] == 7.0), "rows past M were written"
+        outs.append(o[:M])
+    _assert_close(outs[0][rows], y, act)
+    assert np.array_equal(outs[0], outs[1])
+    # the split really happened: the unsplit 128 x 128 path sums in another order (some values differ in the last place)
+    os.environ["MI_GEMM_DMA_SPLITK"] = "0"
+    try:
+        out = torch.full((M, N), 7.0, dtype=xd.dtype, device="cuda")
+        _run(ol, xd, M, act, 1, epi=L.EPI_STORE, out=out, ldo=N)
+    finally:
+        del os.environ["MI_GEMM_DMA_SPLITK"]
+    _assert_close(host(out)[rows], y, act)
+    h = dev(h0, act)
+    _run(ol, xd, M, act, 1, epi=L.EPI_RESID, resid=h, out=h, ldo=N)
+    _assert_close(host(h)[rows], round_to(h0[rows] + y, act), act)
