@@ -266,7 +266,7 @@ def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
             assert np.allclose(got, want, rtol=1e-4, atol=2e-5), np.abs(got - want).max()
         else:
             assert close_frac(got, want, act, atol=1e-3) <= 0.02, close_frac(got, want, act, atol=1e-3)
-        if L_ > 1 and act != "float32" and D >= 32:
+        if L_ > 1 and (D >= 32 if act != "float32" else D % 64 == 0):
             # the LDS-DMA kernel (default) against the register-staged one it replaced: same images, same MFMA order
             out0 = torch.zeros_like(out)
             os.environ["MI_ATTN_PREFILL_DMA"] = "0"
@@ -279,11 +279,13 @@ def test_rope_append_and_attention(act, Hq, Hkv, D, qk_norm, L_):
             assert torch.equal(out, out0), "LDS-DMA prefill attention differs from the register-staged kernel"
 
 
-@pytest.mark.parametrize("act", ["bfloat16", "float16"])
+@pytest.mark.parametrize("act", ["bfloat16", "float16", "float32"])
 @pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64), (5, 1, 32), (8, 1, 128)])
 def test_prefill_attention_many_blocks(act, Hq, Hkv, D):
     """Prefill attention over several hundred keys (the K / V ring of three buffers goes round many times), ragged offsets,
     against the oracle on sampled queries and bit for bit against the register-staged kernel."""
+    if act == "float32" and D % 64 != 0:
+        pytest.skip("float32 caches: the matrix-core prefill kernels take head_dim 64 / 128")
     B, L_, cap = 3, 150, 512
     offs = [0, 333, 97]
     rng = np.random.default_rng(4242)        # (its own stream: the module's RNG feeds the tests below in file order)
@@ -311,7 +313,10 @@ def test_prefill_attention_many_blocks(act, Hq, Hkv, D):
         for t in (0, 1, 15, 16, 31, 32, 77, L_ - 1):
             n = offs[b] + t + 1
             o, _ = ref_model.sdpa(q[b:b + 1, t:t + 1].transpose(0, 2, 1, 3), kc[b:b + 1, :, :n], vc[b:b + 1, :, :n], D ** -0.5, None, act, act)
-            assert close_frac(got[b, t], o[0, :, 0], act, atol=1e-3) <= 0.02, (b, t)
+            if act == "float32":
+                assert np.allclose(got[b, t], o[0, :, 0], rtol=1e-4, atol=2e-5), (b, t)
+            else:
+                assert close_frac(got[b, t], o[0, :, 0], act, atol=1e-3) <= 0.02, (b, t)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
