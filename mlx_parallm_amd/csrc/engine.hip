@@ -47,6 +47,7 @@ struct FusedLinear {
   size_t w_bytes = 0, s_bytes = 0;
   void* w = nullptr; void* scales = nullptr; void* biases = nullptr;
   void* w_hilo = nullptr;        // f16 dense weights in the float32-activation (PagedKVCache) mode: [hi | lo] bf16 copy, made on first use
+  void* w_gu8 = nullptr;         // dense 16-bit gate|up: row-interleaved copy for the decode GEMV (EPI_SWIGLU_GU8), made on first use
   float* lora_a[2] = {nullptr, nullptr};
   float* lora_b[2] = {nullptr, nullptr};
   int seen_w[3] = {0, 0, 0}, seen_s[3] = {0, 0, 0}, seen_b[3] = {0, 0, 0};
@@ -116,6 +117,7 @@ struct mi_engine {
   int opt_short_prefill_skinny = 1;   // short prefill / mixed calls on the weight-streaming kernel instead of the tile GEMM (gemv_rows)
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
   bool sq_valid = false; const void* sq_src = nullptr; int sq_parts = 0, sq_K = 0, sq_ld = 0;
+  bool opt_gu8 = true;                   // decode GEMV of a dense gate|up matrix on its row-interleaved copy: 7 one-tile items per CU instead of 3.5 pairs (twice the matrix's bytes)
   bool opt_f16_hilo = true;              // f16 dense weights in the float32-activation mode through an exact [hi | lo] bf16 copy (matrix cores)
   int opt_fused_pairs = 0;               // bit 0: o_proj -> gate|up, bit 1: down_proj -> next q|k|v as one launch each.
                                          // Off: measured on Mistral-7B bf16 B=8 the in-launch seam costs what the kernel
@@ -265,7 +267,7 @@ int make_f32_copy(mi_engine* e, const void* src, int n, void** dst) {
 }
 
 void free_linear(FusedLinear& f) {
-  hipFree(f.w); hipFree(f.scales); hipFree(f.biases); hipFree(f.w_hilo);
+  hipFree(f.w); hipFree(f.scales); hipFree(f.biases); hipFree(f.w_hilo); hipFree(f.w_gu8);
   for (int i = 0; i < 2; ++i) { hipFree(f.lora_a[i]); hipFree(f.lora_b[i]); }
 }
 
@@ -569,6 +571,14 @@ int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, Gemv
     c.ev_start = a; c.ev_stop = b;
     e->prof_events.emplace_back(a, b);
   }
+  // SwiGLU on the matrix-core GEMV: the row-interleaved copy of the gate|up matrix (made on first use; repack.hip)
+  const bool gu8 = mfma && e->opt_gu8 && c.epi == EPI_SWIGLU && !has_lora && f0.W.layout == 1 &&
+                   (f0.W.wk == WK_BF16 || f0.W.wk == WK_F16) && f0.W.N == 2 * c.pair_offset && c.pair_offset % 16 == 0;
+  if (gu8 && f0.w_gu8 == nullptr) {
+    FusedLinear& fm = const_cast<FusedLinear&>(f0);
+    MI_HIP(hipMalloc(&fm.w_gu8, (size_t)f0.W.N * f0.W.K * sizeof(uint16_t)));
+    MI_TRY(launch_gate_up_interleave(f0.W, c.pair_offset, fm.w_gu8, e->stream));
+  }
   const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
   for (size_t r = 0; r < rows; r += step) {
     GemvCall cc = c;
@@ -579,6 +589,13 @@ int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, Gemv
     if (has_lora) {
       cc.lora_t = e->lora_t + r * 128; cc.lora_t_ld = 128;
       MI_TRY(launch_lora_down(f0.W, cc, e->lora_t + r * 128, 128, e->stream));
+    }
+    if (gu8) {
+      LinearW wv = f0.W;                       // (a view: the copy stays owned by f0)
+      wv.w = f0.w_gu8;
+      cc.epi = EPI_SWIGLU_GU8;
+      MI_TRY(launch_gemv_mfma(wv, cc, e->stream));
+      continue;
     }
     MI_TRY(launch_gemv(f0.W, cc, e->stream));
   }
@@ -1700,6 +1717,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }
   if (k == "f16_hilo") { e->opt_f16_hilo = value != 0; return MI_OK; }
+  if (k == "gate_up_interleave") { e->opt_gu8 = value != 0; return MI_OK; }
   if (k == "seam_spin_limit") {
     if (value < 0 || value > (int64_t)0x7fffffff) return fail(MI_ERR_INVALID, "seam_spin_limit out of range");
     e->seam_spin_limit = (unsigned)value; return MI_OK;

@@ -420,6 +420,17 @@ struct Phase {
             const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
             const float sl = (float)(AT)(gt * sig);
             store_elem<AT>(&out[(size_t)m * p.ldo + n], (AT)(sl * up), WT);
+          } else if (p.epi == EPI_SWIGLU_GU8) {
+            // row-interleaved gate|up tile: columns 0..7 are gate, 8..15 the matching up rows (same reduction order as above)
+            if ((el & 15) < 8) {
+              float yu = 0.f;
+#pragma unroll
+              for (int ww = 0; ww < NW; ++ww) yu += red[((ww * NA + 0) * 64 + el + 8) * 4 + r];
+              const float gt = (float)(AT)y0, up = (float)(AT)yu;
+              const float sig = (float)(AT)(1.0f / (1.0f + expf(-gt)));
+              const float sl = (float)(AT)(gt * sig);
+              store_elem<AT>(&out[(size_t)m * p.ldo + (n >> 4) * 8 + (el & 15)], (AT)(sl * up), WT);
+            }
           } else {
             float y = (float)(AT)y0;
             if (p.lora_t != nullptr) {

@@ -27,6 +27,9 @@ enum : int {
   EPI_STORE_F32 = 1,  // out_f32[m][n] = float(T(acc))            (logits for the sampler)
   EPI_RESID = 2,      // resid[m][n] = T(resid[m][n] + T(acc))     (h = x + r, llama.py:188,190)
   EPI_SWIGLU = 3,     // out[m][n] = T(T(silu(g)) * u), g/u = rows n, n+pair_offset (llama.py:165)
+  EPI_SWIGLU_GU8 = 4, // the same on the row-interleaved copy of a gate|up matrix (tile t = gate rows 8t..8t+7, then up rows
+                      // 8t..8t+7; launch_gate_up_interleave): a PLAIN one-stream GEMV over 2 x pair_offset rows whose
+                      // epilogue pairs columns j and j + 8 of every tile -- gemv_mfma only (decode steps of <= 16 rows)
 };
 
 struct GemvCall {
@@ -122,6 +125,8 @@ size_t tiled_bytes(int wk, int N, int K);
 int launch_repack_tiled(const LinearW& src_row_major, void* dst, hipStream_t st);
 // tile-major f16 (N x K) -> tile-major bf16 [hi | lo] (N x 2K), hi + lo == w exactly (repack.hip); dst: 2 x the source's bytes
 int launch_f16_to_hilo(const LinearW& tiled_f16, void* dst, hipStream_t st);
+// tile-major gate|up (rows [0, I) gate, [I, 2 I) up) -> tile-major with tile t = {gate rows 8t..8t+7, up rows 8t..8t+7}
+int launch_gate_up_interleave(const LinearW& tiled, int pair_offset, void* dst, hipStream_t st);
 
 // byte offset of the 16-byte piece holding W[row][k .. k+8) (k % 8 == 0) of a tile-major dense matrix
 __host__ __device__ inline size_t tiled_piece_dense16(size_t row, int k, int K) {

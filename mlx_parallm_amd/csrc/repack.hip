@@ -207,6 +207,33 @@ __global__ void f16_to_hilo_kernel(const uint16_t* src, uint16_t* dst, int N, in
   }
 }
 
+// Row-interleaved copy of a tile-major gate|up matrix for the decode GEMV (gemv_mfma, EPI_SWIGLU_GU8).  With gate and up
+// as separate 16-row tiles a SwiGLU work item is a PAIR of tiles, and 14336 / 16 = 896 pairs deal 3.5 to each of 256 CUs:
+// half the CUs stream a fourth pair while the others idle (12.5 % of the launch).  Tile t of the copy holds gate rows
+// 8t .. 8t+7 in its rows 0..7 and up rows 8t .. 8t+7 in rows 8..15: 1792 one-tile items, 7 per CU, same bytes per item as
+// any plain tile, and silu(g) * u pairs columns j and j + 8 of one MFMA tile.  16-byte pieces: lane (g, c16) of block
+// (tile, k block) holds 8 k of row c16.
+__global__ __launch_bounds__(256) void gate_up_interleave_kernel(const u32x4* src, u32x4* dst, int I, int kblocks, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int l = (int)(i & 63), c16 = l & 15, g = l >> 4;
+  const size_t blk = i >> 6;
+  const int kb = (int)(blk % kblocks);
+  const int t = (int)(blk / kblocks);
+  const int row = c16 < 8 ? 8 * t + c16 : I + 8 * t + (c16 - 8);
+  dst[i] = src[((size_t)(row >> 4) * kblocks + kb) * 64 + g * 16 + (row & 15)];
+}
+
+int launch_gate_up_interleave(const LinearW& W, int pair_offset, void* dst, hipStream_t st) {
+  if (W.layout != 1 || (W.wk != WK_BF16 && W.wk != WK_F16) || W.N != 2 * pair_offset || pair_offset % 16 != 0 || W.K % 32 != 0)
+    return fail(MI_ERR_INVALID, "gate_up_interleave: a tile-major dense 16-bit gate|up matrix with pair_offset % 16 == 0");
+  const size_t total = (size_t)W.N * W.K * 2 / 16;
+  hipLaunchKernelGGL(gate_up_interleave_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u32x4*)W.w, (u32x4*)dst,
+                     pair_offset, W.K / 32, total);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 int launch_f16_to_hilo(const LinearW& tiled_f16, void* dst, hipStream_t st) {
   if (tiled_f16.wk != WK_F16 || tiled_f16.layout != 1) return fail(MI_ERR_INVALID, "f16_to_hilo: a tile-major f16 matrix is expected");
   hipLaunchKernelGGL(f16_to_hilo_kernel, dim3(2048), dim3(256), 0, st, (const uint16_t*)tiled_f16.w, (uint16_t*)dst, tiled_f16.N, tiled_f16.K);

@@ -101,6 +101,33 @@ def test_float32_kv_prefill_through_the_tile_gemm(tiny_dirs, name, B, L0):
     model.engine.close()
 
 
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_f16", "qwen3_bf16"])
+def test_decode_swiglu_on_the_row_interleaved_gate_up_copy_is_bit_identical(tiny_dirs, name):
+    """Decode steps of <= 16 rows stream a row-interleaved copy of the dense gate|up matrix (tile t = gate rows 8t..8t+7 then
+    up rows 8t..8t+7: one-tile work items, 7 per CU at Mistral-7B's shape instead of 3.5 pairs).  Same K order per column,
+    same cross-wave reduction, same rounding chain of silu(g) * u: the logits must equal the paired-tile kernel's bit for bit."""
+    if name not in tiny_dirs:
+        pytest.skip(f"no tiny model {name}")
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    eng = model.engine
+    for B in (1, 5, 8, 13):
+        toks = _left_pad_prompts(cfg, B, 12)
+        outs = {}
+        for on in (1, 0):
+            eng.set_option("gate_up_interleave", on)
+            kv = eng.new_kv(B, capacity=32, kv_dtype="model")
+            lg = [eng.forward(toks, kv, all_positions=True)[:, -1]]
+            nxt = np.argmax(lg[0], axis=-1)[:, None].astype(np.int32)
+            for _ in range(4):
+                lg.append(eng.forward(nxt, kv))
+                nxt = np.argmax(lg[-1], axis=-1)[:, None].astype(np.int32)
+            outs[on] = np.stack(lg)
+            kv.close()
+        eng.set_option("gate_up_interleave", 1)
+        assert np.array_equal(outs[1], outs[0]), (name, B, np.abs(outs[1] - outs[0]).max())
+    eng.close()
+
+
 def test_f16_model_in_float32_kv_mode_runs_on_the_matrix_cores_and_equals_the_exact_kernels(tiny_dirs):
     """PagedKVCache mode of an f16 model (base.py:111-112 promotes to float32 whatever the model dtype): the linears go
     through an EXACT [hi | lo] bf16 copy of the f16 weights on the float32-activation matrix-core kernels (x split three
