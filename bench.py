@@ -583,7 +583,7 @@ def main():
         if args.workload != "mistral-7b-bf16" or kern != "gemv_gate_up" or B != 8 or args.lora:
             return None, None
         # model-dtype KV: the M <= 8 kernel with the fused RMSNorm; float32 KV: the split-K kernel on float32 activations
-        want = "gemv_mfma_kernel<bf16,dense,MB=8,swiglu>" if kv_dtype == "model" else "skinny_kernel<bf16,0,1,true,true>"
+        want = "gemv_mfma_gu8_kernel<bf16,MB=8>" if kv_dtype == "model" else "skinny_kernel<bf16,0,1,true,true>"
         for tag in (("round3_bf16kv", "round2", "round1") if kv_dtype == "model" else ("round3_f32kv",)):
             vals = {}
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

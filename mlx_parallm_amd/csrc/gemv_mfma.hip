@@ -51,6 +51,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(MfmaParams p) {
   ph.template run<false, false, false>();
 }
 
+// The same body under its own symbol for the launches on a row-interleaved gate|up copy (EPI_SWIGLU_GU8): the dominant
+// kernel of a decode step keeps a name of its own in kernel traces and counter passes (bench.py's roofline block reads it).
+template <typename AT, int MB, int NW, int J, bool DB>
+__global__ __launch_bounds__(NW * 64) void gemv_mfma_gu8_kernel(MfmaParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Phase<AT, false, MB, false, NW, J, DB> ph(p, smem_raw);
+  if (ph.ntiles <= 0) return;
+  ph.template run<false, false, false>();
+}
+
 // Two dependent GEMVs in one launch: A (plain epilogue) then B (SwiGLU or plain), see the file header.
 // grid = number of CUs, every workgroup resident at once (one 8-wave workgroup per CU).
 template <typename AT, bool Q4, int MB, bool SWB, int NW, int JA, int JB>
@@ -83,6 +93,9 @@ int cu_count() {
 template <typename AT, bool Q4, int MB, bool SWIGLU, int NW, int J, bool DB>
 int launch_j(const MfmaParams& p, hipStream_t st) {
   auto kern = gemv_mfma_kernel<AT, Q4, MB, SWIGLU, NW, J, DB>;
+  if constexpr (!Q4 && !SWIGLU) {
+    if (p.epi == EPI_SWIGLU_GU8) kern = gemv_mfma_gu8_kernel<AT, MB, NW, J, DB>;
+  }
   constexpr int NA = SWIGLU ? 2 : 1;
   const size_t lds = phase_lds_bytes<NW, NA, Q4>(p.kc, MB, DB ? 2 : 1);
   MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

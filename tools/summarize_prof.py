@@ -61,6 +61,10 @@ def pretty(name: str) -> str:
         return "gemv_mfma_kernel<%s,%s,MB=%s,%s%s>" % (at, "int4" if m.group(2) == "true" else "dense", m.group(3),
                                                         "swiglu" if m.group(4) == "true" else "plain",
                                                         ",dbuf" if m.group(7) == "true" else "")
+    m = re.match(r"gemv_mfma_gu8_kernel<(\w+), (\d+)", n)
+    if m:
+        at = {"__bf16": "bf16", "_Float16": "f16"}.get(m.group(1), m.group(1))
+        return "gemv_mfma_gu8_kernel<%s,MB=%s>" % (at, m.group(2))
     m = re.match(r"gemm_tile_kernel<(\w+), (true|false)>", n)
     if m:
         at = {"__bf16": "bf16", "_Float16": "f16"}.get(m.group(1), m.group(1))
