@@ -78,6 +78,12 @@ CHECKPOINTS[("mistral-7b", "int8", 15)] = [
     dict(name="wide_mistral_int8_modelkv", paged=False, **MAIN, prompt_seed=118),
     dict(name="wide_mistral_int8_paged", paged=True, **MAIN, prompt_seed=119),
 ]
+# an f16 model at production width (the f16 instantiations of every kernel; in the float32-KV mode: the exact [hi | lo] bf16
+# copy of the f16 weights on the float32-activation matrix-core paths)
+CHECKPOINTS[("mistral-7b", "f16", 16)] = [
+    dict(name="wide_mistral_f16_modelkv", paged=False, **MAIN, prompt_seed=120),
+    dict(name="wide_mistral_f16_paged", paged=True, **MAIN, prompt_seed=121),
+]
 ADAPTER_SEED = 77
 
 

@@ -29,7 +29,7 @@ MAX_POS = 2048
 
 def model_kwargs(family: str, precision: str, seed: int) -> dict:
     kw = dict(FAMILIES[family])
-    kw.update(seed=seed, layers=LAYERS, dtype="bfloat16", tie_word_embeddings=False, weight_std=0.02,
+    kw.update(seed=seed, layers=LAYERS, dtype=("float16" if precision == "f16" else "bfloat16"), tie_word_embeddings=False, weight_std=0.02,
               quantize_model=(precision in ("int4", "int8")), q_bits=(8 if precision == "int8" else 4), q_group_size=64,
               with_tokenizer=False,
               max_position_embeddings=MAX_POS)
