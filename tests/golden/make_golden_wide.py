@@ -80,6 +80,11 @@ CHECKPOINTS[("mistral-7b", "int8", 15)] = [
 ]
 # an f16 model at production width (the f16 instantiations of every kernel; in the float32-KV mode: the exact [hi | lo] bf16
 # copy of the f16 weights on the float32-activation matrix-core paths)
+# config 5 as BASELINE words it: top-p sampling at 64 sequences on the adapted int4 Qwen3-14B (V = 151936), ragged prompts;
+# float32-KV, where the draw can be checked against the oracle's cumulative distribution (full logits of six pairs)
+CHECKPOINTS[("qwen3-14b", "int4", 14)].append(
+    dict(name="wide_qwen3_int4_lora_b64_topp_paged", paged=True, lora=True, B=64, L0=96, steps=6, temp=1.0, top_p=0.9,
+         ragged=True, prompt_seed=122))
 CHECKPOINTS[("mistral-7b", "f16", 16)] = [
     dict(name="wide_mistral_f16_modelkv", paged=False, **MAIN, prompt_seed=120),
     dict(name="wide_mistral_f16_paged", paged=True, **MAIN, prompt_seed=121),
@@ -113,7 +118,8 @@ def run_case(ref, cfg, ck, case):
           f"margins <= 0.13: {int((np.stack(margins) <= 0.13).sum())} of {steps * B}", flush=True)
 
 
-FULL_LOGITS = {"wide_mistral_int4_topp_paged": [(0, 0), (0, 5), (1, 2), (7, 7), (12, 3), (23, 1)]}    # (step, row)
+FULL_LOGITS = {"wide_mistral_int4_topp_paged": [(0, 0), (0, 5), (1, 2), (7, 7), (12, 3), (23, 1)],    # (step, row)
+               "wide_qwen3_int4_lora_b64_topp_paged": [(0, 0), (0, 63), (1, 17), (2, 40), (4, 5), (5, 31)]}
 
 
 def log_softmax64(lg):

@@ -116,7 +116,7 @@ def checkpoints(tmp_path_factory):
 
 
 def test_wide_golden_files_present():
-    assert len(WIDE) >= 21, "run tests/golden/make_golden_wide.py"
+    assert len(WIDE) >= 22, "run tests/golden/make_golden_wide.py"
     assert len(SERVING) >= 4, "run tests/golden/make_golden_serving.py"
     missing = [p.stem for p in WIDE if envelope_of(p.stem) is None]
     assert not missing, f"run tests/golden/make_golden_wide.py --envelope {' '.join(missing)}"
