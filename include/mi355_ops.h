@@ -92,12 +92,6 @@ int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int kspli
  * nn.Linear over B x L rows at once).  a->M rows of 16-bit activations, tile-major dense 16-bit weights, a->pro =
  * MI_PRO_NONE; plain / residual / SwiGLU epilogues.  iters >= 1 also times that many back-to-back launches into *avg_ms. */
 int mi_op_gemm_prefill(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
-/* chain.hip on its own: up to 4 dependent linears (a[i].x may be what a[i-1] wrote: wait_prev[i] != 0) of a decode step of
- * a[0].M <= 8 rows as ONE persistent launch; tile-major dense 16-bit weights.  Replaces the o_proj / gate|up / down_proj /
- * next q|k|v launches of a decoder block (llama.py:143,165,188-190,64-67).  iters >= 1 also times that many back-to-back
- * launches into *avg_ms; *error_out receives the kernel's give-up code (0 = every bounded wait was satisfied). */
-int mi_op_chain(const mi_op_linear* const* w, const mi_op_gemv_args* a, const int32_t* wait_prev, int nops, int iters,
-                float* avg_ms, int32_t* error_out);
 /* tile-major weight layout of the streaming kernels (what mi_engine_finalize applies to eligible
  * matrices): returns the size of the tiled buffer (0 if the matrix is not eligible) / fills `dst`. */
 uint64_t mi_op_tiled_bytes(const mi_op_linear* row_major);

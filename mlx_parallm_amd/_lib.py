@@ -111,8 +111,6 @@ SIGNATURES = {
     "mi_op_gemm_skinny": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_int), C.c_int,
                                     C.POINTER(C.c_float)]),
     "mi_op_gemm_prefill": (C.c_int, [C.POINTER(OpLinear), C.POINTER(OpGemvArgs), C.c_int, C.POINTER(C.c_float)]),
-    "mi_op_chain": (C.c_int, [C.POINTER(C.POINTER(OpLinear)), C.POINTER(OpGemvArgs), C.POINTER(C.c_int32), C.c_int, C.c_int,
-                              C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "mi_op_tiled_bytes": (C.c_uint64, [C.POINTER(OpLinear)]),
     "mi_op_repack_tiled": (C.c_int, [C.POINTER(OpLinear), _P]),
     "mi_op_embed": (C.c_int, [C.POINTER(OpLinear), _P, C.c_int, C.c_int, C.c_int, _P]),

@@ -46,8 +46,12 @@ struct FusedLinear {
   int dense_dtype = -1, scale_dtype = -1;
   size_t w_bytes = 0, s_bytes = 0;
   void* w = nullptr; void* scales = nullptr; void* biases = nullptr;
-  void* w_hilo = nullptr;        // f16 dense weights in the float32-activation (PagedKVCache) mode: [hi | lo] bf16 copy, made on first use
-  void* w_gu8 = nullptr;         // dense 16-bit gate|up: row-interleaved copy for the decode GEMV (EPI_SWIGLU_GU8), made on first use
+  // Persistent second copies of a matrix (made by mi_engine_finalize, i.e. BEFORE a scheduler sizes its KV arena from the
+  // free device memory; a pointer is published only after its repack launch succeeded; when the allocation fails the
+  // copy is marked unavailable and the linear keeps its plain path -- ensure_hilo / ensure_gu8)
+  void* w_hilo = nullptr;        // f16 dense weights in the float32-activation (PagedKVCache) mode: [hi | lo] bf16 copy
+  void* w_gu8 = nullptr;         // dense 16-bit gate|up: row-interleaved copy for the decode GEMV (EPI_SWIGLU_GU8)
+  bool hilo_failed = false, gu8_failed = false;
   float* lora_a[2] = {nullptr, nullptr};
   float* lora_b[2] = {nullptr, nullptr};
   int seen_w[3] = {0, 0, 0}, seen_s[3] = {0, 0, 0}, seen_b[3] = {0, 0, 0};
@@ -326,6 +330,37 @@ int ensure_workspace(mi_engine* e, size_t rows, size_t logit_rows, int B) {
   return MI_OK;
 }
 
+// ---- persistent weight copies.  Both return true when the copy exists afterwards.  A failed allocation is not an error of
+// the call: the runtime's error state is cleared, the copy is marked unavailable for this linear and the caller uses the
+// path that reads the matrix as loaded.  The pointer is published only once the repack kernel has been enqueued successfully
+// (same stream as every consumer).
+bool hilo_wanted(const mi_engine* e, const FusedLinear& f) {
+  return f.W.wk == WK_F16 && f.W.layout == 1 && e->opt_f16_hilo && !e->opt_force_v1 && f.W.K % 256 == 0;
+}
+bool ensure_hilo(mi_engine* e, FusedLinear& f) {
+  if (f.w_hilo != nullptr) return true;
+  if (f.hilo_failed || !hilo_wanted(e, f)) return false;
+  void* p = nullptr;
+  if (hipMalloc(&p, 2 * (size_t)f.W.N * f.W.K * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); f.hilo_failed = true; return false; }
+  if (launch_f16_to_hilo(f.W, p, e->stream) != MI_OK) { hipFree(p); f.hilo_failed = true; return false; }
+  f.w_hilo = p;
+  return true;
+}
+bool gu8_wanted(const mi_engine* e, const FusedLinear& f, int pair_offset) {
+  const bool has_lora = f.W.lora_b[0] != nullptr || f.W.lora_b[1] != nullptr;
+  return e->opt_gu8 && !e->opt_force_v1 && !has_lora && f.W.layout == 1 && (f.W.wk == WK_BF16 || f.W.wk == WK_F16) &&
+         f.W.N == 2 * pair_offset && pair_offset % 16 == 0;
+}
+bool ensure_gu8(mi_engine* e, FusedLinear& f, int pair_offset) {
+  if (f.w_gu8 != nullptr) return true;
+  if (f.gu8_failed || !gu8_wanted(e, f, pair_offset)) return false;
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)f.W.N * f.W.K * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); f.gu8_failed = true; return false; }
+  if (launch_gate_up_interleave(f.W, pair_offset, p, e->stream) != MI_OK) { hipFree(p); f.gu8_failed = true; return false; }
+  f.w_gu8 = p;
+  return true;
+}
+
 // y = W x for `rows` rows, split into launches of at most 16 (MFMA) / 8 (generic) rows
 int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, GemvCall c, size_t rows, size_t es_in, size_t es_out,
                  const char* prof, bool sq_was_valid);
@@ -336,16 +371,12 @@ int gemv_rows(mi_engine* e, const FusedLinear& f0, GemvCall c, size_t rows, size
   e->sq_valid = false;
   // An f16 model in the PagedKVCache mode (float32 activations): the matrix-core kernels of that mode multiply an exact
   // three-way bf16 split of x by bf16 weights, so an f16 matrix is used through its exact [hi | lo] bf16 copy (2 K
-  // columns, x walked twice: GemvCall::kx) -- made here on first use, twice the matrix's bytes.  Everything that is
+  // columns, x walked twice: GemvCall::kx) -- made by mi_engine_finalize (here only if the option was switched on later),
+  // twice the matrix's bytes; without it (allocation failed) the exact VALU kernel reads the f16 matrix.  Everything that is
   // about x (norms, LoRA down-projection, the split) keeps the true K of f0.
-  if (c.act == MI_F32 && f0.W.wk == WK_F16 && f0.W.layout == 1 && e->opt_f16_hilo && !e->opt_force_v1 && f0.W.K % 256 == 0) {
-    FusedLinear& fm = const_cast<FusedLinear&>(f0);
-    if (fm.w_hilo == nullptr) {
-      MI_HIP(hipMalloc(&fm.w_hilo, 2 * (size_t)f0.W.N * f0.W.K * sizeof(uint16_t)));
-      MI_TRY(launch_f16_to_hilo(f0.W, fm.w_hilo, e->stream));
-    }
+  if (c.act == MI_F32 && hilo_wanted(e, f0) && ensure_hilo(e, const_cast<FusedLinear&>(f0))) {
     FusedLinear fh = f0;                       // (a view: the pointers stay owned by f0)
-    fh.W.wk = WK_BF16; fh.W.w = fm.w_hilo; fh.W.K = 2 * f0.W.K;
+    fh.W.wk = WK_BF16; fh.W.w = f0.w_hilo; fh.W.K = 2 * f0.W.K;
     c.kx = f0.W.K;
     return gemv_rows_on(e, fh, f0, c, rows, es_in, es_out, prof, sq_was_valid);
   }
@@ -571,14 +602,10 @@ int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, Gemv
     c.ev_start = a; c.ev_stop = b;
     e->prof_events.emplace_back(a, b);
   }
-  // SwiGLU on the matrix-core GEMV: the row-interleaved copy of the gate|up matrix (made on first use; repack.hip)
-  const bool gu8 = mfma && e->opt_gu8 && c.epi == EPI_SWIGLU && !has_lora && f0.W.layout == 1 &&
-                   (f0.W.wk == WK_BF16 || f0.W.wk == WK_F16) && f0.W.N == 2 * c.pair_offset && c.pair_offset % 16 == 0;
-  if (gu8 && f0.w_gu8 == nullptr) {
-    FusedLinear& fm = const_cast<FusedLinear&>(f0);
-    MI_HIP(hipMalloc(&fm.w_gu8, (size_t)f0.W.N * f0.W.K * sizeof(uint16_t)));
-    MI_TRY(launch_gate_up_interleave(f0.W, c.pair_offset, fm.w_gu8, e->stream));
-  }
+  // SwiGLU on the matrix-core GEMV: the row-interleaved copy of the gate|up matrix (repack.hip; made by mi_engine_finalize,
+  // here only if the option was switched on later; without it the paired-tile form below)
+  const bool gu8 = mfma && c.epi == EPI_SWIGLU && gu8_wanted(e, f0, c.pair_offset) &&
+                   ensure_gu8(e, const_cast<FusedLinear&>(f0), c.pair_offset);
   const char* x0 = (const char*)c.x; char* o0 = (char*)c.out; char* r0 = (char*)c.resid;
   for (size_t r = 0; r < rows; r += step) {
     GemvCall cc = c;
@@ -1271,9 +1298,13 @@ int mi_engine_finalize(mi_engine* e) {
     MI_TRY(make_f32_copy(e, l.post_norm, H, &l.post_norm32));
     MI_TRY(make_f32_copy(e, l.q_norm, d.head_dim, &l.q_norm32));
     MI_TRY(make_f32_copy(e, l.k_norm, d.head_dim, &l.k_norm32));
+    // persistent second copies, while mem_get_info still tells a scheduler the truth about what is left for its KV arena
+    (void)ensure_gu8(e, l.gate_up, d.intermediate_size);
+    if (d.act_dtype == MI_F16) { (void)ensure_hilo(e, l.qkv); (void)ensure_hilo(e, l.o); (void)ensure_hilo(e, l.gate_up); (void)ensure_hilo(e, l.down); }
   }
   MI_TRY(finalize_linear(e, e->embed, H, "model.embed_tokens"));
   if (!d.tie_word_embeddings) MI_TRY(finalize_linear(e, e->lm_head, H, "lm_head"));
+  if (d.act_dtype == MI_F16) (void)ensure_hilo(e, d.tie_word_embeddings ? e->embed : e->lm_head);
   if (!e->final_norm) return fail(MI_ERR_NOTFOUND, "model.norm.weight not set");
   MI_TRY(make_f32_copy(e, e->final_norm, H, &e->final_norm32));
   const size_t n = (size_t)d.max_positions * (d.head_dim / 2);

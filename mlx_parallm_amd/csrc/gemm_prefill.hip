@@ -734,6 +734,7 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+#ifdef MI_GEMM_M32_BUILD      // a debug build target (hipcc -DMI_GEMM_M32_BUILD, run with MI_GEMM_M32=1): measured 7 % slower than the 16 x 16 x 32 form, not in the shipped library
 template <typename AT, bool SWIGLU>
 __global__ __launch_bounds__(512) void gemm_tile256_m32_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
@@ -877,6 +878,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_m32_kernel(GemmParams p) {
       }
     }
 }
+#endif  // MI_GEMM_M32_BUILD
 
 // out[row][:] = w * cast_T(x32 * rsqrt(mean(x32^2) + eps))   (nn.RMSNorm); one wave per row
 template <typename AT>
@@ -1155,15 +1157,22 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     const int bn = sw ? 128 : BN2;
     dim3 grid2(((int)rows + BM2 - 1) / BM2, (ncols + bn - 1) / bn), block2(512);
     if (ks256 > 1) { grid2.z = ks256; p.ksplit = ks256; p.ws = (float*)splitk_ws; }
+#ifdef MI_GEMM_M32_BUILD
     static const bool m32 = getenv("MI_GEMM_M32") != nullptr;               // A/B: the 32x32x16 form of the tile
+#endif
     const bool use_dma = dma && p.K >= 2 * BK;
+#ifdef MI_GEMM_M32_BUILD
+#define GO256_M32(T, S) else if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \
+        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
+        hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); }
+#else
+#define GO256_M32(T, S)
+#endif
 #define GO256(T, S) do { \
       if (use_dma) { auto k = gemm_dma256_kernel<T, S>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DMA_BUF)); \
         hipLaunchKernelGGL(k, grid2, block2, 2 * DMA_BUF, st, p); } \
-      else if (m32) { auto k = gemm_tile256_m32_kernel<T, S>; \
-        MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
-        hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } \
+      GO256_M32(T, S) \
       else if (b_in_lds) { auto k = gemm_tile256_kernel<T, S, false>; \
         MI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES)); \
         hipLaunchKernelGGL(k, grid2, block2, LDS2_BYTES, st, p); } \

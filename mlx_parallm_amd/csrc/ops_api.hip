@@ -138,54 +138,6 @@ int mi_op_gemm_prefill(const mi_op_linear* w, const mi_op_gemv_args* a, int iter
   return rc != MI_OK ? rc : rc2;
 }
 
-int mi_op_chain(const mi_op_linear* const* w, const mi_op_gemv_args* a, const int32_t* wait_prev, int nops, int iters,
-                float* avg_ms, int32_t* error_out) {
-  if (!w || !a || !wait_prev || nops < 1 || nops > 4) return fail(MI_ERR_INVALID, "bad argument");
-  MI_TRY(ready());
-  LinearW W[4]; GemvCall c[4]; const LinearW* Wp[4]; int wp[4];
-  float* sq[4] = {nullptr, nullptr, nullptr, nullptr};
-  for (int i = 0; i < nops; ++i) { W[i] = to_linear(w[i]); c[i] = to_call(&a[i]); Wp[i] = &W[i]; wp[i] = wait_prev[i]; }
-  // a normalised linear takes its row statistics from the residual epilogue in front of it (sums of h^2 per 16-column tile)
-  for (int i = 1; i < nops; ++i) {
-    if (c[i].pro == PRO_NORM && wp[i] && c[i - 1].epi == EPI_RESID && c[i - 1].resid == c[i].x && W[i - 1].N == W[i].K) {
-      MI_HIP(hipMalloc(&sq[i], (size_t)chain_sq_ld(W[i].K) * 8 * sizeof(float)));
-      MI_HIP(hipMemset(sq[i], 0, (size_t)chain_sq_ld(W[i].K) * 8 * sizeof(float)));
-      c[i - 1].sq_out = sq[i]; c[i].sq_in = sq[i]; c[i].sq_parts = chain_sq_ld(W[i].K);
-    }
-  }
-  for (int i = 0; i < nops; ++i)
-    if (!chain_linear_ok(W[i], c[i])) return fail(MI_ERR_UNSUPPORTED, "mi_op_chain: linear not supported by the chain kernel");
-  unsigned* ctr = nullptr; int* err = nullptr;
-  MI_HIP(hipMalloc(&ctr, CHAIN_CTR_WORDS * sizeof(unsigned)));
-  MI_HIP(hipMalloc(&err, sizeof(int)));
-  MI_HIP(hipMemset(ctr, 0, CHAIN_CTR_WORDS * sizeof(unsigned)));
-  MI_HIP(hipMemset(err, 0, sizeof(int)));
-  unsigned base = 0;
-  const unsigned spin = 1u << 22;
-  int rc = launch_chain(Wp, c, wp, nops, c[0].M, c[0].act, ctr, base, spin, err, nullptr);
-  base += (unsigned)chain_grid();
-  if (rc == MI_OK && iters >= 1 && avg_ms) {
-    hipStreamSynchronize(nullptr);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && rc == MI_OK; ++i) { rc = launch_chain(Wp, c, wp, nops, c[0].M, c[0].act, ctr, base, spin, err, nullptr); base += (unsigned)chain_grid(); }
-    hipEventRecord(e1, nullptr);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    *avg_ms = ms / iters;
-    hipEventDestroy(e0); hipEventDestroy(e1);
-  }
-  const int rc2 = finish();
-  int herr = 0;
-  hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
-  if (error_out) *error_out = herr;
-  hipFree(ctr); hipFree(err);
-  for (int i = 0; i < 4; ++i) hipFree(sq[i]);
-  return rc != MI_OK ? rc : rc2;
-}
-
 int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a) {
   if (!w || !a) return 0;
   return gemv_mfma_supported(to_linear(w), to_call(a)) ? 1 : 0;

@@ -191,9 +191,15 @@ def gpu_preload_in_environment(env: Optional[Dict[str, str]] = None) -> str:
     pre = env.get("LD_PRELOAD", "")
     if any(k in pre for k in ("rocprof", "roctracer", "rocprofiler")):
         return "LD_PRELOAD=" + pre
-    for key in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB"):
+    for key in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIB"):
         if env.get(key):
             return f"{key}={env[key]}"
+    # HSA_TOOLS_LIB is loaded by hsa_init, which a launcher that never touches the GPU never calls: a debug agent or
+    # tracer named there has not initialised anything in THIS process -- worth a note, not a refusal
+    if env.get("HSA_TOOLS_LIB"):
+        import sys
+
+        print(f"note: HSA_TOOLS_LIB={env['HSA_TOOLS_LIB']} is set; the rank processes will load it at hsa_init", file=sys.stderr)
     return ""
 
 

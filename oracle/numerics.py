@@ -130,6 +130,98 @@ def _accum_gemm_lib():
     return _accum_lib or None
 
 
+_exact_lib = None
+
+
+def _exact_gemm_lib():
+    """oracle/c/exact_gemm.c (built by oracle/c/Makefile): exactly-summed matmuls straight from compact weights -- what
+    makes a 32- / 40-block production-width model fit this container (tests/golden/make_golden_wide.py, the *_full_* cases)."""
+    global _exact_lib
+    if _exact_lib is None:
+        import ctypes as C
+        from pathlib import Path
+
+        path = Path(__file__).resolve().parent / "_build" / "libexact_gemm.so"
+        if not path.exists():
+            _exact_lib = False
+        else:
+            lib = C.CDLL(str(path))
+            lib.exact_gemm_nt_w16.restype = None
+            lib.exact_gemm_nt_w16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_long]
+            lib.exact_qgemm_nt.restype = None
+            lib.exact_qgemm_nt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_long, C.c_long, C.c_long]
+            lib.dequant_q_f32.restype = None
+            lib.dequant_q_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long]
+            lib.widen_w16_f32.restype = None
+            lib.widen_w16_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+            _exact_lib = lib
+    return _exact_lib or None
+
+
+W16_KIND = {"bfloat16": 0, "float16": 1}
+
+
+def widen_w16(bits: np.ndarray, dtype: str) -> np.ndarray:
+    """16-bit patterns (uint16) of `dtype` -> float32 values."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint16)
+    lib = _exact_gemm_lib()
+    if lib is not None:
+        out = np.empty(bits.shape, np.float32)
+        lib.widen_w16_f32(bits.ctypes.data, W16_KIND[dtype], out.ctypes.data, bits.size)
+        return out
+    if dtype == "bfloat16":
+        return bf16_bits_to_f32(bits)
+    return bits.view(np.float16).astype(np.float32)
+
+
+def matmul_nt_w16(x: np.ndarray, bits: np.ndarray, dtype: str) -> np.ndarray:
+    """matmul_nt against a 16-bit weight matrix kept as its bit patterns (N, K): double products, double sum, one rounding."""
+    lib = _exact_gemm_lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if lib is None or x2.shape[0] > 32:              # many rows (a prefill): BLAS on a transient float64 copy is faster
+        return matmul_nt(x, widen_w16(bits, dtype))
+    bits = np.ascontiguousarray(bits, dtype=np.uint16)
+    y = np.empty((x2.shape[0], bits.shape[0]), np.float32)
+    lib.exact_gemm_nt_w16(x2.ctypes.data, bits.ctypes.data, W16_KIND[dtype], y.ctypes.data, x2.shape[0], bits.shape[0], K)
+    return y.reshape(*x.shape[:-1], bits.shape[0])
+
+
+def dequant_f32(packed, scales, biases, group: int, bits: int):
+    """oracle/ref_quant.py:dequantize through C when it is built (None otherwise): the same float32 w_hat, two roundings."""
+    lib = _exact_gemm_lib()
+    if lib is None:
+        return None
+    packed = np.ascontiguousarray(packed, dtype=np.uint32)
+    scales = np.ascontiguousarray(scales, dtype=np.float32)
+    biases = np.ascontiguousarray(biases, dtype=np.float32)
+    N, K = packed.shape[0], packed.shape[1] * 32 // bits
+    out = np.empty((N, K), np.float32)
+    lib.dequant_q_f32(packed.ctypes.data, scales.ctypes.data, biases.ctypes.data, bits, group, out.ctypes.data, N, K)
+    return out
+
+
+def matmul_nt_q(x: np.ndarray, packed, scales, biases, group: int, bits: int):
+    """matmul_nt against MLX-affine quantised weights, w_hat formed on the fly (None when the C library is not built or the
+    call has many rows: the caller then dequantises and uses matmul_nt)."""
+    lib = _exact_gemm_lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if lib is None or x2.shape[0] > 32:
+        return None
+    packed = np.ascontiguousarray(packed, dtype=np.uint32)
+    scales = np.ascontiguousarray(scales, dtype=np.float32)
+    biases = np.ascontiguousarray(biases, dtype=np.float32)
+    N = packed.shape[0]
+    y = np.empty((x2.shape[0], N), np.float32)
+    lib.exact_qgemm_nt(x2.ctypes.data, packed.ctypes.data, scales.ctypes.data, biases.ctypes.data, bits, group, y.ctypes.data,
+                       x2.shape[0], N, K)
+    return y.reshape(*x.shape[:-1], N)
+
+
 def matmul_nt_f32(x: np.ndarray, w: np.ndarray, mode: str, use_c: bool = True) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)

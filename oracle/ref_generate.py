@@ -36,13 +36,32 @@ def _load_safetensors(path: str) -> Dict[str, Tuple[np.ndarray, str]]:
     return out
 
 
-def load_weights(model_dir: str, cfg_dict: dict) -> Dict[str, object]:
+def _load_safetensors_compact(path: str) -> Dict[str, Tuple[np.ndarray, str]]:
+    """As _load_safetensors, but 16-bit matrices stay 16-bit patterns (uint16, dtype kept in the tag as "w16:<dtype>"): the
+    full-depth production-width checkpoints do not fit this container as float32 (ref_model.COMPACT)."""
+    import torch
+    from safetensors import safe_open
+
+    out = {}
+    with safe_open(path, framework="pt") as f:
+        for k in f.keys():
+            t = f.get_tensor(k)
+            if t.dtype in (torch.uint32, torch.int32):
+                out[k] = (t.view(torch.int32).numpy().view(np.uint32), "uint32")
+            elif t.ndim == 2 and t.dtype in (torch.bfloat16, torch.float16) and not (k.endswith(".scales") or k.endswith(".biases")):
+                out[k] = (t.contiguous().view(torch.int16).numpy().view(np.uint16), "w16:" + _TORCH_DT[str(t.dtype)])
+            else:
+                out[k] = (t.to(torch.float32).numpy(), _TORCH_DT[str(t.dtype)])
+    return out
+
+
+def load_weights(model_dir: str, cfg_dict: dict, compact: bool = False) -> Dict[str, object]:
     files = sorted(glob.glob(str(Path(model_dir) / "model*.safetensors")))
     if not files:
         raise FileNotFoundError(f"No safetensors found in {model_dir}")          # utils.py:663-665
     raw: Dict[str, Tuple[np.ndarray, str]] = {}
     for f in files:
-        raw.update(_load_safetensors(f))
+        raw.update(_load_safetensors_compact(f) if compact else _load_safetensors(f))
     q = cfg_dict.get("quantization")
     w: Dict[str, object] = {}
     for name, (arr, dt) in raw.items():
@@ -56,6 +75,8 @@ def load_weights(model_dir: str, cfg_dict: dict) -> Dict[str, object]:
                                  group_size=int(q["group_size"]), bits=int(q["bits"]))
             elif arr.ndim == 1:
                 w[base] = (arr, dt)                                               # RMSNorm weight
+            elif dt.startswith("w16:"):
+                w[base] = Linear(dtype=dt[4:], w16=arr)
             else:
                 w[base] = Linear(dtype=dt, weight=arr)
     return w
@@ -81,7 +102,7 @@ def apply_adapters(weights: Dict[str, object], n_layers: int, adapter_dir: str) 
             lin.lora_scale = float(lp["scale"])
 
 
-def load(model_dir: str, adapter_path: Optional[str] = None, max_pos: int = 4096) -> RefModel:
+def load(model_dir: str, adapter_path: Optional[str] = None, max_pos: int = 4096, compact: bool = False) -> RefModel:
     cfg_path = Path(model_dir) / "config.json"
     if not cfg_path.exists():
         raise FileNotFoundError(str(cfg_path))                                    # utils.py:620-627
@@ -89,7 +110,7 @@ def load(model_dir: str, adapter_path: Optional[str] = None, max_pos: int = 4096
     if {"mistral": "llama"}.get(cfg_dict["model_type"], cfg_dict["model_type"]) not in ("llama", "qwen3"):
         raise ValueError(f"Model type {cfg_dict['model_type']} not supported.")   # utils.py:60-65
     cfg = RefConfig.from_dict(cfg_dict)
-    weights = load_weights(model_dir, cfg_dict)
+    weights = load_weights(model_dir, cfg_dict, compact=compact)
     if adapter_path is not None:
         apply_adapters(weights, cfg.num_hidden_layers, adapter_path)
     return RefModel(cfg, weights, max_pos=max_pos)

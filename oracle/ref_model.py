@@ -26,6 +26,9 @@ from .ref_quant import dequantize
 
 
 CACHE_F64 = False      # speed only: keep a float64 copy of every weight matrix (make_golden_wide.py sets it)
+COMPACT = False        # memory only (full-depth goldens): weights stay in their checkpoint storage (16-bit patterns / packed
+                       # codes); dense float32 / float64 copies are made per call and dropped, small-row calls go through
+                       # oracle/c/exact_gemm.c.  Same arithmetic as the default path (tests/test_oracle_units.py).
 
 
 def promote(a: str, b: str) -> str:
@@ -40,6 +43,7 @@ class Linear:
     """nn.Linear / nn.QuantizedLinear (no bias on this path: llama.py:64-67, qwen3.py:37-40)."""
     dtype: str                       # dtype of weight (dense) or of scales (quantised)
     weight: Optional[np.ndarray] = None        # dense (N, K) float32 values representable in dtype
+    w16: Optional[np.ndarray] = None           # COMPACT: the same matrix as uint16 bit patterns of `dtype` (weight is None)
     packed: Optional[np.ndarray] = None        # quantised (N, K*bits/32) uint32
     scales: Optional[np.ndarray] = None
     biases: Optional[np.ndarray] = None
@@ -55,15 +59,31 @@ class Linear:
     def dense(self) -> np.ndarray:
         if self.weight is not None:
             return self.weight
+        if self.w16 is not None:
+            return numerics.widen_w16(self.w16, self.dtype)              # transient
+        if COMPACT:
+            w = numerics.dequant_f32(self.packed, self.scales, self.biases, self.group_size, self.bits)
+            return w if w is not None else dequantize(self.packed, self.scales, self.biases, self.group_size, self.bits)
         if self._dense_cache is None:
             self._dense_cache = dequantize(self.packed, self.scales, self.biases,
                                            self.group_size, self.bits)
         return self._dense_cache
 
+    def _matmul(self, x: np.ndarray) -> np.ndarray:
+        """x @ W.T, exactly summed (or under the accumulation envelope's float32 orders)."""
+        if numerics.ACCUM == "exact" and COMPACT:
+            if self.w16 is not None:
+                return numerics.matmul_nt_w16(x, self.w16, self.dtype)
+            if self.weight is None:
+                y = numerics.matmul_nt_q(x, self.packed, self.scales, self.biases, self.group_size, self.bits)
+                if y is not None:
+                    return y
+        return matmul_nt(x, self.dense64() if numerics.ACCUM == "exact" else self.dense())
+
     def dense64(self) -> np.ndarray:
         """float64 copy of ``dense()`` when CACHE_F64 is on (same values; saves the per-call widening of a
         production-width matrix in the decode steps of tests/golden/make_golden_wide.py)."""
-        if not CACHE_F64:
+        if not CACHE_F64 or COMPACT:
             return self.dense()
         if self._dense64 is None:
             self._dense64 = self.dense().astype(np.float64)
@@ -72,7 +92,7 @@ class Linear:
     def __call__(self, x: np.ndarray, xdt: str):
         """x @ W.T with fp32 accumulation; output dtype = result_type(x, W) (App. A.1)."""
         odt = promote(xdt, self.dtype)
-        y = round_to(matmul_nt(x, self.dense64() if numerics.ACCUM == "exact" else self.dense()), odt)
+        y = round_to(self._matmul(x), odt)
         if self.lora_a is not None:
             # y + (scale * ((x @ A) @ B)).astype(x.dtype)     (App. A.6)
             zdt = promote(xdt, self.lora_dtype)
@@ -89,6 +109,8 @@ class Linear:
         """nn.Embedding / nn.QuantizedEmbedding lookup: rows of the (de)quantised table."""
         if self.weight is not None:
             return self.weight[ids], self.dtype
+        if self.w16 is not None:
+            return numerics.widen_w16(self.w16[ids.reshape(-1)], self.dtype).reshape(*ids.shape, -1), self.dtype
         # dequantise only the gathered rows: round_T(scale*q + bias)
         w = dequantize(self.packed[ids.reshape(-1)], self.scales[ids.reshape(-1)],
                        self.biases[ids.reshape(-1)], self.group_size, self.bits)

@@ -89,7 +89,37 @@ CHECKPOINTS[("mistral-7b", "f16", 16)] = [
     dict(name="wide_mistral_f16_modelkv", paged=False, **MAIN, prompt_seed=120),
     dict(name="wide_mistral_f16_paged", paged=True, **MAIN, prompt_seed=121),
 ]
+# FULL DEPTH (round 4): every decoder block of the real models (llama.py:228 / qwen3.py:182 loop over all layers) -- 32 for
+# Mistral-7B, 40 for Qwen3-14B -- at a context the CPU oracle can afford: depth is where accumulation error grows, and the
+# envelope above had only been shown 2 blocks deep.  The checkpoints (14.5 GB bf16 / 8.3 GB int4) are drawn per tensor
+# (wide_models.build_checkpoint_streamed) and the oracle keeps them in their storage format (ref_model.COMPACT,
+# oracle/c/exact_gemm.c).  The 4th key element is the number of blocks.
+FULL = dict(B=2, L0=128, steps=16, temp=0.0, top_p=1.0)
+CHECKPOINTS[("mistral-7b", "bf16", 31, 32)] = [
+    dict(name="wide_mistral_bf16_full_modelkv", paged=False, **FULL, prompt_seed=131),
+    dict(name="wide_mistral_bf16_full_paged", paged=True, **FULL, prompt_seed=132),
+]
+CHECKPOINTS[("qwen3-14b", "int4", 32, 40)] = [
+    dict(name="wide_qwen3_int4_full_modelkv", paged=False, **FULL, prompt_seed=133),
+    dict(name="wide_qwen3_int4_full_paged", paged=True, **FULL, prompt_seed=134),
+]
+CHECKPOINTS[("mistral-7b", "int4", 33, 32)] = [
+    dict(name="wide_mistral_int4_full_modelkv", paged=False, **FULL, prompt_seed=135),
+    dict(name="wide_mistral_int4_full_paged", paged=True, **FULL, prompt_seed=136),
+]
+CHECKPOINTS[("qwen3-14b", "bf16", 34, 40)] = [
+    dict(name="wide_qwen3_bf16_full_modelkv", paged=False, **FULL, prompt_seed=137),
+    dict(name="wide_qwen3_bf16_full_paged", paged=True, **FULL, prompt_seed=138),
+]
 ADAPTER_SEED = 77
+
+
+def load_ref(d, ck):
+    """-> (cfg, oracle model) of checkpoint key ck built in directory d; full-depth keys load compact."""
+    full = len(ck) > 3
+    ref_model.COMPACT = full
+    cfg = wide_models.build_checkpoint(d, *ck)
+    return cfg, ref_generate.load(d, max_pos=wide_models.MAX_POS, compact=full)
 
 
 def run_case(ref, cfg, ck, case):
@@ -108,7 +138,8 @@ def run_case(ref, cfg, ck, case):
         tv = np.take_along_axis(logits, order, axis=-1)
         top_vals.append(tv)
         margins.append(tv[:, 0] - tv[:, 1])
-    spec = dict(case, family=ck[0], precision=ck[1], model_seed=ck[2], adapter_seed=ADAPTER_SEED)
+    spec = dict(case, family=ck[0], precision=ck[1], model_seed=ck[2], adapter_seed=ADAPTER_SEED,
+                layers=(ck[3] if len(ck) > 3 else wide_models.LAYERS))
     np.savez_compressed(
         OUT / f"{case['name']}.npz", spec=json.dumps(spec), uniforms=uniforms,
         tokens=np.stack(toks).astype(np.int32), logprobs=np.stack(lps).astype(np.float32),
@@ -212,8 +243,7 @@ def main():
             if not cases:
                 continue
             with tempfile.TemporaryDirectory() as d:
-                cfg = wide_models.build_checkpoint(d, *ck)
-                ref = ref_generate.load(d, max_pos=wide_models.MAX_POS)
+                cfg, ref = load_ref(d, ck)
                 adapted = False
                 for case in cases:
                     if case.get("lora") and not adapted:
@@ -223,7 +253,7 @@ def main():
                         adapted = True
                     assert bool(case.get("lora")) == adapted, "adapter runs must come last"
                     if logits and case["name"] in FULL_LOGITS:
-                        ref_model.CACHE_F64 = True
+                        ref_model.CACHE_F64 = len(ck) == 3
                         run_full_logits(ref, cfg, ck, case)
                         ref_model.CACHE_F64 = False
                     if envelope:
@@ -236,8 +266,7 @@ def main():
             continue
         with tempfile.TemporaryDirectory() as d:
             t0 = time.time()
-            cfg = wide_models.build_checkpoint(d, *ck)
-            ref = ref_generate.load(d, max_pos=wide_models.MAX_POS)
+            cfg, ref = load_ref(d, ck)
             print(f"checkpoint {ck}: built + loaded in {time.time() - t0:.0f} s", flush=True)
             adapted = False
             for case in cases:

@@ -88,18 +88,6 @@ def gemv_args(x, M, act, *, pro=0, norm_w=None, eps=0.0, epi=0, out=None, ldo=0,
     return a
 
 
-def chain(linears, args, wait_prev, iters=0):
-    """chain.hip on its own (mi_op_chain): -> (kernel give-up code, mean launch ms or None)."""
-    n = len(linears)
-    lp = (C.POINTER(L.OpLinear) * n)(*[C.pointer(ol) for ol in linears])
-    aa = (L.OpGemvArgs * n)(*args)
-    wp = (C.c_int32 * n)(*[int(w) for w in wait_prev])
-    ms, err = C.c_float(0.0), C.c_int32(0)
-    torch.cuda.synchronize()
-    L.check(L.lib().mi_op_chain(lp, aa, wp, n, int(iters), C.byref(ms), C.byref(err)))
-    return int(err.value), (ms.value if iters >= 1 else None)
-
-
 def attn_shape(B, L_, Hq, Hkv, D, act, kv, rnd, cap) -> L.OpAttnShape:
     s = L.OpAttnShape()
     s.B, s.L, s.Hq, s.Hkv, s.D, s.act, s.kv, s.rnd, s.cap = B, L_, Hq, Hkv, D, MIDT[act], MIDT[kv], rnd, cap

@@ -46,8 +46,9 @@ def test_bench_gpus_2_as_a_plain_command_runs_two_ranks_with_engines():
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"
     assert j["broadcast_buckets"] >= 1 and j["broadcast_bytes"] > 0 and j["broadcast_seconds"] > 0
     assert j["value"] > 0 and abs(j["value"] - 2 * 2 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 0.01
-    assert "reference_numerics" in j and j["reference_numerics"]["value"] > 0
-    assert "float32" in j["reference_numerics"]["what"]
+    # the headline leg is the reference's numerics (float32 KV); the 16-bit-KV leg rides along as fast_mode
+    assert "float32" in j["config"]["kv_dtype"] and "fast_mode" in j and j["fast_mode"]["value"] > 0
+    assert "BatchedKVCache" in j["fast_mode"]["what"] and "reference_numerics" not in j
     pr = j["per_rank_tokens_per_sec"]                      # each rank's own K steps: min <= max, and the job total is at most the sum
     assert 0 < pr["min"] <= pr["max"] and j["value"] <= 2 * pr["max"] * 1.01
 

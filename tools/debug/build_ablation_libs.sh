@@ -4,6 +4,7 @@
 #   tools/debug/build_ablation_libs.sh        (in the build container; the .so files travel with the snapshot)
 set -e
 cd "$(dirname "$0")/../../mlx_parallm_amd/csrc"
+make -s
 mkdir -p alt
 for A in NOFMA NOUNPACK NOSTAGE NOSX "NOFMA -DMI_ABL_NOUNPACK -DMI_ABL_NOSTAGE -DMI_ABL_NOSX"; do
   tag=$(echo "$A" | tr -d ' ' | sed 's/-DMI_ABL_/_/g' | tr 'A-Z' 'a-z')
@@ -12,6 +13,7 @@ done
 wait
 for f in alt/gemm_skinny_abl_*.o; do
   tag=$(basename $f .o | sed 's/gemm_skinny_abl_//')
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 engine.o gemv_v1.o gemv_mfma.o gemm_prefill.o $f attn.o attn_decode.o attn_prefill.o misc.o repack.o ops_api.o -o alt/libmi355_abl_$tag.so
+  # every product object except gemm_skinny.o (the list follows the Makefile's sources, whatever they are this round)
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(ls *.o | grep -v '^gemm_skinny\.o$') $f -o alt/libmi355_abl_$tag.so
 done
 ls -la alt/*.so

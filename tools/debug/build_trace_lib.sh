@@ -8,5 +8,5 @@ mkdir -p alt
 for f in gemm_skinny gemv_mfma attn_decode; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMI_SK_TRACE $TRACE_FLAGS -c $f.hip -o alt/${f}_trace.o
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 engine.o gemv_v1.o alt/gemv_mfma_trace.o gemm_prefill.o alt/gemm_skinny_trace.o attn.o alt/attn_decode_trace.o attn_prefill.o misc.o repack.o ops_api.o -o alt/libmi355_trace.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(ls *.o | grep -v -e '^gemv_mfma\.o$' -e '^gemm_skinny\.o$' -e '^attn_decode\.o$') alt/gemv_mfma_trace.o alt/gemm_skinny_trace.o alt/attn_decode_trace.o -o alt/libmi355_trace.so
 echo built alt/libmi355_trace.so

@@ -51,7 +51,8 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "gemv_phase.h"
+#include "../../../mlx_parallm_amd/csrc/gemv_phase.h"
+#include "chain.h"
 
 namespace mi {
 

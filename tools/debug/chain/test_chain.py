@@ -1,4 +1,7 @@
-"""-m gpu: chain.hip -- the linear layers of one decoder block's decode step (o_proj + residual, RMSNorm + gate|up + SwiGLU,
+"""DEBUG BUILD ONLY (not collected by the test suite: the chain kernel is not in libmi355_decode.so).  Run on a GPU box:
+    bash tools/debug/build_chain_lib.sh          (in the build container)
+    MLX_PARALLM_AMD_LIB=$PWD/mlx_parallm_amd/csrc/alt/libmi355_chain.so python -m pytest tools/debug/chain/test_chain.py -m gpu -q
+chain.hip -- the linear layers of one decoder block's decode step (o_proj + residual, RMSNorm + gate|up + SwiGLU,
 down_proj + residual, RMSNorm + the next block's q|k|v) as ONE persistent launch with a weight-loader wave per CU --
 against the same four linears run as the engine's single launches (mi_op_gemv, themselves oracle-checked in
 test_gpu_kernels.py) and against the oracle's arithmetic, at the Mistral-7B and Qwen3-14B layer shapes and at a small
@@ -9,8 +12,32 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from gpu_helpers import chain, dev, gemv, gemv_args, host, op_linear, to_tiled  # noqa: E402
+import ctypes as C  # noqa: E402
+import sys  # noqa: E402
+from pathlib import Path  # noqa: E402
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[3] / "tests"))
+from gpu_helpers import dev, gemv, gemv_args, host, op_linear, to_tiled  # noqa: E402
 from mlx_parallm_amd import _lib as L  # noqa: E402
+
+
+def chain(linears, args, wait_prev, iters=0):
+    """chain.hip on its own (mi_op_chain): -> (kernel give-up code, mean launch ms or None)."""
+    n = len(linears)
+    lp = (C.POINTER(L.OpLinear) * n)(*[C.pointer(ol) for ol in linears])
+    aa = (L.OpGemvArgs * n)(*args)
+    wp = (C.c_int32 * n)(*[int(w) for w in wait_prev])
+    ms, err = C.c_float(0.0), C.c_int32(0)
+    torch.cuda.synchronize()
+    fn = L.lib().mi_op_chain           # (only the debug library exports it)
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.POINTER(L.OpLinear)), C.POINTER(L.OpGemvArgs), C.POINTER(C.c_int32), C.c_int, C.c_int,
+                   C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.check(fn(lp, aa, wp, n, int(iters), C.byref(ms), C.byref(err)))
+    return int(err.value), (ms.value if iters >= 1 else None)
+
+
+
 from oracle.numerics import matmul_nt, round_to  # noqa: E402
 
 RNG = np.random.default_rng(11)

@@ -20,7 +20,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ROOT/bench.py "$@" --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/stats.err"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ROOT/bench.py "$@" --no-cpu-baseline --no-other-configs > "$OUT/bench.json" 2> "$OUT/stats.err"
 python3 "$ROOT/tools/summarize_prof.py" stats "$OUT/stats" "$ROOT/gpurun_out/${TAG}_kernel_stats.csv" "rocprofv3 --kernel-trace --stats -- python3 bench.py $*"
 grep '^{' "$OUT/bench.json" > "$ROOT/gpurun_out/${TAG}_bench.json"
 rm -rf "$OUT/stats"
