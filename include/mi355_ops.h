@@ -85,7 +85,10 @@ int mi_op_gemv_uses_mfma(const mi_op_linear* w, const mi_op_gemv_args* a);
 int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters, float* avg_ms);
 /* the split-K weight-streaming GEMM the engine uses for decode steps of 9..128 rows (int4 / int8 weights: 1..128), on its own:
  * a->M in that range, a->pro = MI_PRO_NONE, tile-major 16-bit, int4 or int8 (group 64) weights.  ksplit 0 = the library's
- * cost model (returned in *ksplit_used); iters >= 1 also times that many back-to-back launches into *avg_ms. */
+ * cost model (returned in *ksplit_used); iters >= 1 also times that many back-to-back launches into *avg_ms.
+ * int4 weights above 16 rows with ksplit <= 0 run the round-4 kernel (gemm_q4.hip: x prepared once per launch, K split
+ * over the waves of a workgroup; a->pro may then be MI_PRO_NORM); ksplit < 0 forces its plan for tests and A/B runs:
+ * -(row_tiles | tile_units << 3 | k_lanes << 7 | ksplit << 11 | staging_waves << 15), any field 0 = the cost model's choice. */
 int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters,
                       float* avg_ms);
 /* gemm_prefill.hip on its own: the tile GEMM of the prefill call (generate_step's first model call, utils.py:243-262: every

@@ -460,8 +460,9 @@ int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, Gemv
     // float32 activations without logical rounding (PagedKVCache mode after layer 0): the kernel applies the row scale
     // of the RMSNorm in its epilogue (gemm_skinny.hip "defer_norm") -- no norm launch, nothing waits for row statistics
     const bool defer = e->opt_defer_norm && c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && !handed;
+    const bool q4_prep = gemm_q4_supported(f.W, c, rows);      // gemm_q4.hip: its preparation pass over x applies the RMSNorm
     if (handed) { c.sq_in = e->d_sq; c.sq_parts = e->sq_parts; }
-    else if (c.pro == PRO_NORM && !defer) {
+    else if (c.pro == PRO_NORM && !defer && !q4_prep) {
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, KT, (int)rows, KT, c.eps, c.act, e->stream, true, c.rnd));
       c.x = e->xn; c.ldx = KT; c.pro = PRO_NONE;
     }

@@ -961,8 +961,12 @@ bool gemm_skinny_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   return n % 16 == 0;
 }
 
-size_t gemm_skinny_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ws_bytes; }
+size_t gemm_skinny_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows) {
+  if (gemm_q4_supported(W, c, rows)) return gemm_q4_ws_bytes(W, c, rows);
+  return skinny_plan(W, c, rows).ws_bytes;
+}
 int gemm_skinny_groups(const LinearW& W, const GemvCall& c, size_t rows) {      // arrival counters the launch needs
+  if (gemm_q4_supported(W, c, rows)) return gemm_q4_groups(W, c, rows);
   const SkinnyPlan pl = skinny_plan(W, c, rows);
   return pl.ngroups * pl.nslab;
 }
@@ -1007,6 +1011,7 @@ extern "C" int mi_debug_sk_trace_dump(const char* path) {
 #endif
 
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr, int ksplit) {
+  if (ksplit <= 0 && gemm_q4_supported(W, c, rows)) return launch_gemm_q4(W, c, rows, st, ws, ctr);     // int4 above 16 rows (gemm_q4.hip)
   const bool defer_norm = c.pro == PRO_NORM && c.act == MI_F32 && c.rnd == RND_NONE && c.norm_w != nullptr;
   if (c.pro != PRO_NONE && !defer_norm && !(gemm_skinny_handover_ld(W, c, rows) > 0 && c.sq_in != nullptr && c.sq_parts > 0))
     return fail(MI_ERR_INVALID, "gemm_skinny: normalise the activations first (or hand over the row sums of squares)");
@@ -1068,7 +1073,10 @@ int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStre
   return c.act == MI_BF16 ? launch_at<bf16>(p, qb, sw, pl.mt, grid, st) : launch_at<f16>(p, qb, sw, pl.mt, grid, st);
 }
 
-int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) { return skinny_plan(W, c, rows).ksplit; }
+int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) {
+  if (gemm_q4_supported(W, c, rows)) return gemm_q4_ksplit(W, c, rows);
+  return skinny_plan(W, c, rows).ksplit;
+}
 
 // RMSNorm hand-over between two launches: row stride of the [tile groups][ld] table of sums of squares that this call would
 // write (residual epilogue) or read (PRO_NORM) -- its rows padded to whole workgroups -- or 0 when its instantiation
@@ -1076,6 +1084,7 @@ int gemm_skinny_ksplit(const LinearW& W, const GemvCall& c, size_t rows) { retur
 // hand-over must agree on it.
 int gemm_skinny_handover_ld(const LinearW& W, const GemvCall& c, size_t rows) {
   if (c.act == MI_F32) return 0;
+  if (gemm_q4_supported(W, c, rows)) return 0;
   const SkinnyPlan pl = skinny_plan(W, c, rows);
   if (pl.mt != 1 && !(pl.mt == 2 && !wk_is_quant(W.wk))) return 0;
   return pl.nslab * 16 * pl.mt;

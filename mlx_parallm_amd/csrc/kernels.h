@@ -108,6 +108,16 @@ int gemm_skinny_tile_groups(const LinearW& W, const GemvCall& c, size_t rows);
 int launch_gemm_skinny(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr,
                        int ksplit = 0);
 
+// int4 (group 64) weights, 17..128 rows of 16-bit activations (gemm_q4.hip): x prepared once per launch (fragment-major,
+// with the RMSNorm of c.pro = PRO_NORM applied there), K split over the waves of a workgroup.  launch_gemm_skinny routes
+// to it; `ws` >= gemm_q4_ws_bytes() (preparation buffers + partial tiles), `ctr` >= gemm_q4_groups() zeroed words.
+bool gemm_q4_supported(const LinearW& W, const GemvCall& c, size_t rows);
+size_t gemm_q4_ws_bytes(const LinearW& W, const GemvCall& c, size_t rows);
+int gemm_q4_groups(const LinearW& W, const GemvCall& c, size_t rows);
+int gemm_q4_ksplit(const LinearW& W, const GemvCall& c, size_t rows);
+void gemm_q4_force(int code);     // test / A-B hook: mt | TW << 3 | KW << 7 | ksplit << 11 | NS << 15 for this thread's next plans; 0 clears
+int launch_gemm_q4(const LinearW& W, const GemvCall& c, size_t rows, hipStream_t st, void* ws, unsigned* ctr);
+
 // tile-major weight layout (repack.hip)
 bool tiled_supported(int wk, int N, int K, int group);
 size_t tiled_bytes(int wk, int N, int K);

@@ -1,4 +1,6 @@
 // ops_api.hip -- kernel-level C entry points (include/mi355_ops.h) on caller-owned device buffers.
+#include <algorithm>
+
 #include "../../include/mi355_ops.h"
 #include "kernels.h"
 
@@ -79,19 +81,28 @@ int mi_op_gemv_bench(const mi_op_linear* w, const mi_op_gemv_args* a, int iters,
 }
 
 // gemm_skinny.hip on its own: a->M in 9..128 (int4 / int8: 1..128), a->pro must be MI_PRO_NONE; ksplit 0 = the cost model's choice
-// (*ksplit_used returns it); iters >= 1 additionally times `iters` back-to-back launches.
+// (*ksplit_used returns it); iters >= 1 additionally times `iters` back-to-back launches.  int4 weights above 16 rows with
+// ksplit <= 0 run gemm_q4.hip (a->pro may then be MI_PRO_NORM); ksplit < 0 forces its plan: -(mt | TW << 3 | KW << 7 | ksplit << 11 | NS << 15).
 int mi_op_gemm_skinny(const mi_op_linear* w, const mi_op_gemv_args* a, int ksplit, int* ksplit_used, int iters, float* avg_ms) {
   if (!w || !a) return fail(MI_ERR_INVALID, "null argument");
   MI_TRY(ready());
   const LinearW W = to_linear(w);
   const GemvCall c = to_call(a);
-  if (!gemm_skinny_supported(W, c, (size_t)c.M)) return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_skinny: call not supported by this kernel");
-  const int groups = gemm_skinny_groups(W, c, (size_t)c.M);
+  struct ForceGuard { bool on; ~ForceGuard() { if (on) gemm_q4_force(0); } } guard{ksplit < 0};
+  if (ksplit < 0) {
+    gemm_q4_force(-ksplit);
+    if (!gemm_q4_supported(W, c, (size_t)c.M)) return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_skinny: ksplit < 0 forces gemm_q4, which does not take this call");
+  }
+  if (!gemm_skinny_supported(W, c, (size_t)c.M) && !gemm_q4_supported(W, c, (size_t)c.M))
+    return fail(MI_ERR_UNSUPPORTED, "mi_op_gemm_skinny: call not supported by this kernel");
+  const int groups = std::max(1, gemm_skinny_groups(W, c, (size_t)c.M));
   void* ws = nullptr; unsigned* ctr = nullptr;
-  MI_HIP(hipMalloc(&ws, (size_t)W.N * 8192 + 1024));                  // 16 slices x N x 128 rows x 4 B: any ksplit
+  // 16 slices x N x 128 rows x 4 B: any ksplit of gemm_skinny; gemm_q4: its preparation buffers + partial tiles
+  MI_HIP(hipMalloc(&ws, std::max((size_t)W.N * 8192 + 1024, gemm_skinny_ws_bytes(W, c, (size_t)c.M))));
   MI_HIP(hipMalloc(&ctr, (size_t)groups * sizeof(unsigned)));
   MI_HIP(hipMemset(ctr, 0, (size_t)groups * sizeof(unsigned)));
   if (ksplit_used) *ksplit_used = ksplit > 0 ? ksplit : gemm_skinny_ksplit(W, c, (size_t)c.M);
+  if (ksplit < 0) ksplit = 0;
   int rc = launch_gemm_skinny(W, c, (size_t)c.M, nullptr, ws, ctr, ksplit);
   if (rc == MI_OK && iters >= 1 && avg_ms) {
     hipEvent_t e0, e1;

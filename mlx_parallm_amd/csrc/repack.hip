@@ -162,7 +162,9 @@ bool tiled_supported(int wk, int N, int K, int group) {
 size_t tiled_bytes(int wk, int N, int K) {
   if (wk == WK_BF16 || wk == WK_F16) return (size_t)N * K * 2;
   if (wk == WK_Q8_BF16 || wk == WK_Q8_F16) return (size_t)(N / 16) * (K / 64) * 1088;
-  return (size_t)(N / 16) * (K / 128) * 1152;
+  // (+ 64 KiB: gemm_q4.hip's weight stream is clamp-free -- its prefetch runs up to ~48 blocks past a slice's end, i.e. past
+  // the last tile's end for the last workgroups; what it loads there is never multiplied)
+  return (size_t)(N / 16) * (K / 128) * 1152 + ((size_t)64 << 10);
 }
 
 int launch_repack_tiled(const LinearW& src, void* dst, hipStream_t st) {

@@ -100,12 +100,20 @@ def close_frac(got: np.ndarray, want: np.ndarray, dtype: str, atol: float = 0.0)
     return float(np.mean(np.abs(got - want) > tol))
 
 
+def q4_force(mt=0, tw=0, kw=0, ksplit=0, ns=0) -> int:
+    """`ksplit` argument of gemm_skinny() that forces gemm_q4.hip's plan (include/mi355_ops.h): row tiles per workgroup, tile
+    units x K lanes (= compute waves), K slices over workgroups, staging waves; 0 = the cost model's choice."""
+    return -(mt | tw << 3 | kw << 7 | ksplit << 11 | ns << 15)
+
+
 def gemm_skinny(ol: L.OpLinear, x, M, act, *, epi=0, out=None, ldo=0, resid=None, pair_offset=0, ksplit=0, iters=0, ldx=None,
-                rnd=0):
-    """gemm_skinny.hip on its own (17..64 rows) -> (ksplit used, mean launch ms or None)."""
+                rnd=0, norm_w=None, eps=0.0):
+    """gemm_skinny.hip / gemm_q4.hip on its own (17..128 rows) -> (ksplit used, mean launch ms or None).  norm_w: RMSNorm in
+    front (int4 weights above 16 rows only: gemm_q4.hip's preparation pass applies it)."""
     a = L.OpGemvArgs()
     a.x = x.data_ptr(); a.ldx = ldx if ldx is not None else x.shape[-1]; a.M = M
-    a.act = MIDT[act]; a.rnd = rnd; a.pro = 0; a.epi = epi; a.norm_w = 0; a.eps = 0.0; a.ldo = ldo
+    a.act = MIDT[act]; a.rnd = rnd; a.pro = 1 if norm_w is not None else 0; a.epi = epi
+    a.norm_w = norm_w.data_ptr() if norm_w is not None else 0; a.eps = eps; a.ldo = ldo
     a.out = out.data_ptr() if out is not None else 0
     a.resid = resid.data_ptr() if resid is not None else 0
     a.pair_offset = pair_offset; a.force_generic = 0

@@ -91,7 +91,12 @@ def test_every_wide_case_has_its_accumulation_envelope():
             assert summ[mode]["id_flips"] == int((e[f"argmax_{mode}"] != g["top_ids"][:, :, 0]).sum())
         # the two orders are different arithmetic: they do not coincide, and neither is far from the exact oracle
         assert summ["seq32_vs_pairwise"]["max_lp"] > 0
-        assert max(summ["f32_seq32"]["max_lp"], summ["f32_pairwise"]["max_lp"]) <= (0.1 if not json.loads(str(g["spec"]))["paged"] else 2e-2)
+        # (16-bit mode: errors are whole one-ulp flips of 16-bit values, and they add up like a random walk over the decoder
+        # blocks -- the 2-block cases stay under 0.1, the full-depth ones (32 / 40 blocks, round 4) under 0.1 * sqrt(blocks / 2):
+        # measured 0.16 / 0.19.  The float32-KV bound does not move with depth: 1.4e-3 at full depth.)
+        spec = json.loads(str(g["spec"]))
+        depth = (spec.get("layers", 2) / 2.0) ** 0.5
+        assert max(summ["f32_seq32"]["max_lp"], summ["f32_pairwise"]["max_lp"]) <= (0.1 * depth if not spec["paged"] else 2e-2)
 
 
 def test_full_logits_of_the_sampled_case_are_the_oracles():

@@ -11,23 +11,24 @@ from oracle.numerics import matmul_nt, round_to
 pytestmark = pytest.mark.gpu
 
 from mlx_parallm_amd import _lib as L  # noqa: E402
-from gpu_helpers import dev, dev_u32, gemm_skinny, gemv, host, op_linear, to_tiled  # noqa: E402
+from gpu_helpers import dev, dev_u32, gemm_skinny, gemv, host, op_linear, q4_force, to_tiled  # noqa: E402
 from test_gpu_kernels import _assert_close  # noqa: E402
 
 RNG = np.random.default_rng(4321)
 
 
-def _weight(kind, N, K):
+def _weight(kind, N, K, rng=None):
+    rng = RNG if rng is None else rng
     if kind in ("bf16", "f16"):
         dt = {"bf16": "bfloat16", "f16": "float16"}[kind]
-        w = round_to(RNG.standard_normal((N, K)).astype(np.float32) * 0.05, dt)
+        w = round_to(rng.standard_normal((N, K)).astype(np.float32) * 0.05, dt)
         wd = dev(w, dt)
         ol, keep = op_linear(kind, N, K, wd), [wd]
         assert to_tiled(ol, keep)
         return ol, w, keep
     sdt = {"bf16": "bfloat16", "f16": "float16"}[kind.split("_")[1]]
     bits = 8 if kind.startswith("q8") else 4
-    w = RNG.standard_normal((N, K)).astype(np.float32) * 0.05
+    w = rng.standard_normal((N, K)).astype(np.float32) * 0.05
     packed, scales, biases = ref_quant.quantize(round_to(w, sdt), 64, bits, sdt)
     pd, sd, bd = dev_u32(packed), dev(scales, sdt), dev(biases, sdt)
     ol, keep = op_linear(kind, N, K, pd, sd, bd), [pd, sd, bd]
@@ -95,6 +96,80 @@ def test_epilogues(act, kind):
     out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
     gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE_F32, out=out, ldo=N, ksplit=2)
     _assert_close(host(out), round_to(matmul_nt(x, wdense), act), act)
+
+
+# ---- gemm_q4.hip (round 4): int4 weights above 16 rows -- x prepared once per launch (fragment-major + group sums, RMSNorm
+# applied there), K split over the waves of a workgroup, two tiles per wave, row slabs, optional K slices over workgroups.
+# Plans of every kind the host may choose are forced here: (row tiles per workgroup, tile units x K lanes = compute waves,
+# K slices over workgroups, staging waves).
+RNG_Q4 = np.random.default_rng(4322)       # (a stream of its own: the module stream keeps feeding the older tests the data they had)
+Q4_PLANS = [(1, 1, 8, 1, 4), (1, 8, 1, 1, 2), (2, 2, 4, 1, 4), (2, 4, 2, 2, 2), (2, 8, 1, 1, 2), (3, 4, 2, 1, 4), (4, 4, 2, 1, 4),
+            (4, 8, 1, 3, 2), (2, 1, 4, 1, 4), (2, 5, 2, 1, 2), (4, 2, 2, 2, 4), (2, 3, 2, 1, 2), (4, 10, 1, 1, 2)]
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "q4_bf16"), ("float16", "q4_f16")])
+@pytest.mark.parametrize("mt,tw,kw,ks,ns", Q4_PLANS)
+def test_q4_plans_match_oracle(act, kind, mt, tw, kw, ks, ns):
+    """(M, N, K): ragged rows (not a multiple of 16), an odd number of tiles, K blocks that do not divide by the K lanes,
+    more than one tile group."""
+    for M, N, K in [(17, 80, 640), (61, 272, 1152), (64, 2064, 1024), (100, 144, 896), (128, 96, 2560)]:
+        if (K // 128) // ks < kw or mt > (M + 15) // 16 or mt > 2:
+            continue                                             # (the host never makes such a plan: fewer blocks than K lanes; 3 / 4 row tiles are SwiGLU-only)
+        ol, wdense, keep = _weight(kind, N, K, RNG_Q4)
+        x = round_to(RNG_Q4.standard_normal((M, K)).astype(np.float32), act)
+        xd = dev(x, act)
+        outs = []
+        for _ in range(2):
+            out = torch.full((M + 2, N), 7.0, dtype=xd.dtype, device="cuda")
+            gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE, out=out, ldo=N, ksplit=q4_force(mt, tw, kw, ks, ns))
+            outs.append(host(out))
+        assert np.array_equal(outs[0], outs[1]), (M, N, K)        # fixed reduction orders: run-to-run identical
+        assert np.all(outs[0][M:] == 7.0)
+        _assert_close(outs[0][:M], round_to(matmul_nt(x, wdense), act), act)
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "q4_bf16"), ("float16", "q4_f16")])
+@pytest.mark.parametrize("mt,tw,kw,ks,ns", [(2, 4, 2, 1, 4), (4, 4, 2, 1, 4), (2, 2, 4, 2, 4), (1, 8, 1, 1, 2), (3, 4, 2, 1, 4)])
+def test_q4_norm_prologue_and_epilogues(act, kind, mt, tw, kw, ks, ns):
+    M, eps = max(48, 16 * mt), 1e-5
+    from oracle import ref_model
+
+    def normed(x, nw):
+        return ref_model.rms_norm(x, act, nw, act, eps)[0]
+
+    # RMSNorm in front (llama.py:175-177) + residual add (llama.py:188,190)
+    N, K = 192, 2048
+    ol, wdense, keep = _weight(kind, N, K, RNG_Q4)
+    x = round_to(RNG_Q4.standard_normal((M, K)).astype(np.float32) * 0.5, act)
+    nw = round_to(1.0 + 0.1 * RNG_Q4.standard_normal(K).astype(np.float32), act)
+    h = round_to(RNG_Q4.standard_normal((M, N)).astype(np.float32), act)
+    want = round_to(h + round_to(matmul_nt(normed(x, nw), wdense), act), act)
+    xd, hd, nwd = dev(x, act), dev(h, act), dev(nw, act)
+    if mt <= 2:                                                  # (3 / 4 row tiles per workgroup: the SwiGLU instantiation only)
+        gemm_skinny(ol, xd, M, act, epi=L.EPI_RESID, resid=hd, ldo=N, ksplit=q4_force(mt, tw, kw, ks, ns), norm_w=nwd, eps=eps)
+        _assert_close(host(hd), want, act, scale=4.0)
+    # SwiGLU over a fused gate|up matrix (llama.py:165), RMSNorm in front
+    I, K = 176, 768
+    ol, wdense, keep = _weight(kind, 2 * I, K, RNG_Q4)
+    x = round_to(RNG_Q4.standard_normal((M, K)).astype(np.float32), act)
+    nw = round_to(1.0 + 0.1 * RNG_Q4.standard_normal(K).astype(np.float32), act)
+    xn = normed(x, nw)
+    g = round_to(matmul_nt(xn, wdense[:I]), act)
+    u = round_to(matmul_nt(xn, wdense[I:]), act)
+    sig = round_to(1.0 / (1.0 + np.exp(-g.astype(np.float64))), act)
+    want = round_to(round_to(g * sig, act) * u, act)
+    xd, nwd = dev(x, act), dev(nw, act)
+    out = torch.zeros((M, I), dtype=xd.dtype, device="cuda")
+    if (K // 128) // ks >= kw:
+        gemm_skinny(ol, xd, M, act, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, ksplit=q4_force(mt, tw, kw, ks, ns), norm_w=nwd, eps=eps)
+        _assert_close(host(out), want, act)
+    # float32 logits (lm_head), no norm
+    N = 208
+    ol, wdense, keep = _weight(kind, N, K, RNG_Q4)
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    if (K // 128) // ks >= kw and mt <= 2:
+        gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE_F32, out=out, ldo=N, ksplit=q4_force(mt, tw, kw, ks, ns))
+        _assert_close(host(out), round_to(matmul_nt(x, wdense), act), act)
 
 
 def test_rows_agree_with_the_16_row_kernel():
