@@ -415,6 +415,20 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// P as TWO 16-bit operands (round 4): hi = T(p), lo = T(p - hi).  The reference's attention keeps the softmax numerators in
+// float32 (App. A.4); feeding them to the matrix core as ONE 16-bit value was a rounding the oracle does not have -- the
+// CPU variant with that rounding (oracle/numerics.py SDPA_P16) reproduces the 1.05 - 1.33 x excess of the device's mean
+// |logprob - exact| over the float32-accumulating variants.  hi + lo carries 16+ mantissa bits; the second
+// MFMA per V tile costs ~0.2 us per launch.
+template <typename T>
+__device__ __forceinline__ void pack2_split(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const T ha = (T)a, hb = (T)b;
+  T h[2] = {ha, hb};
+  T l[2] = {(T)(a - (float)ha), (T)(b - (float)hb)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 template <int G, int D, int ES = 2, int NWV = 8>
 __host__ __device__ constexpr size_t attn_mfma_vimg_bytes() { return ES == 2 ? (size_t)NWV * 32 * D * 2 : 0; }   // float32 caches: no V image
 
@@ -733,7 +747,13 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - mn); l_run += p[t][r]; }
-    const u32x4 pf = {pack2<T>(p[0][0], p[0][1]), pack2<T>(p[0][2], p[0][3]), pack2<T>(p[1][0], p[1][1]), pack2<T>(p[1][2], p[1][3])};
+    uint32_t ph[4], pw[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      pack2_split<T>(p[t][0], p[t][1], ph[2 * t], pw[2 * t]);
+      pack2_split<T>(p[t][2], p[t][3], ph[2 * t + 1], pw[2 * t + 1]);
+    }
+    const u32x4 pf = {ph[0], ph[1], ph[2], ph[3]}, pl = {pw[0], pw[1], pw[2], pw[3]};
     // V rows -> this wave's image [16-d tile][key][16 d]
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -754,6 +774,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
       const uint32_t* w1 = (const uint32_t*)&v1;
       const u32x4 vf = {w0[0], w0[1], w1[0], w1[1]};
       accO[dt] = mfma_kq<T>(vf, pf, accO[dt]);
+      accO[dt] = mfma_kq<T>(vf, pl, accO[dt]);
     }
   }
   }

@@ -39,6 +39,15 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 template <typename T>
+__device__ __forceinline__ void pack2_split(float a, float b, uint32_t& hi, uint32_t& lo) {   // as in attn_decode.hip
+  const T ha = (T)a, hb = (T)b;
+  T h[2] = {ha, hb};
+  T l[2] = {(T)(a - (float)ha), (T)(b - (float)hb)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+template <typename T>
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   T v[2] = {(T)a, (T)b};
   return __builtin_bit_cast(uint32_t, v);
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(G * 64, 2) void attn_prefill_kernel(AttnCall c) {
         for (int u = 0; u < QG; ++u) sc[u][t] = mfma16<T>(kf, qf[u][kk], sc[u][t]);
       }
     }
-    u32x4 pf[QG];
+    u32x4 pf[QG], pl[QG];                             // P = hi + lo, two 16-bit operands (attn_decode.hip pack2_split)
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
       // The vector ALU, not the matrix core, bounds this loop (~110 vector instructions + 9 transcendentals per 16 MFMAs
@@ -192,7 +201,14 @@ __global__ __launch_bounds__(G * 64, 2) void attn_prefill_kernel(AttnCall c) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[u][t][r], sc2, -mn)); l_run[u] += p[t][r]; }
-      pf[u] = u32x4{pack2<T>(p[0][0], p[0][1]), pack2<T>(p[0][2], p[0][3]), pack2<T>(p[1][0], p[1][1]), pack2<T>(p[1][2], p[1][3])};
+      uint32_t ph[4], pw[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        pack2_split<T>(p[t][0], p[t][1], ph[2 * t], pw[2 * t]);
+        pack2_split<T>(p[t][2], p[t][3], ph[2 * t + 1], pw[2 * t + 1]);
+      }
+      pf[u] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+      pl[u] = u32x4{pw[0], pw[1], pw[2], pw[3]};
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -203,7 +219,10 @@ __global__ __launch_bounds__(G * 64, 2) void attn_prefill_kernel(AttnCall c) {
       const uint32_t* w1 = (const uint32_t*)&v1;
       const u32x4 vf = {w0[0], w0[1], w1[0], w1[1]};
 #pragma unroll
-      for (int u = 0; u < QG; ++u) accO[u][dt] = mfma16<T>(vf, pf[u], accO[u][dt]);
+      for (int u = 0; u < QG; ++u) {
+        accO[u][dt] = mfma16<T>(vf, pf[u], accO[u][dt]);
+        accO[u][dt] = mfma16<T>(vf, pl[u], accO[u][dt]);
+      }
     }
     if (j + 1 < nb) store_block(buf ^ 1, knext, vnext);   // the other buffer: nobody reads it during this block
     __syncthreads();
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(G * 64, G >= 2 ? 2 : 1) void attn_prefill_dma_kerne
         for (int u = 0; u < QG; ++u) sc[u][t] = mfma16<T>(kf, qf[u][kk], sc[u][t]);
       }
     }
-    u32x4 pf[QG];
+    u32x4 pf[QG], pl[QG];                             // P = hi + lo, two 16-bit operands (attn_decode.hip pack2_split)
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
       // The vector ALU, not the matrix core, bounds this loop (~110 vector instructions + 9 transcendentals per 16 MFMAs
@@ -383,7 +402,14 @@ __global__ __launch_bounds__(G * 64, G >= 2 ? 2 : 1) void attn_prefill_dma_kerne
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[u][t][r], sc2, -mn)); l_run[u] += p[t][r]; }
-      pf[u] = u32x4{pack2<T>(p[0][0], p[0][1]), pack2<T>(p[0][2], p[0][3]), pack2<T>(p[1][0], p[1][1]), pack2<T>(p[1][2], p[1][3])};
+      uint32_t ph[4], pw[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        pack2_split<T>(p[t][0], p[t][1], ph[2 * t], pw[2 * t]);
+        pack2_split<T>(p[t][2], p[t][3], ph[2 * t + 1], pw[2 * t + 1]);
+      }
+      pf[u] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+      pl[u] = u32x4{pw[0], pw[1], pw[2], pw[3]};
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -394,7 +420,10 @@ __global__ __launch_bounds__(G * 64, G >= 2 ? 2 : 1) void attn_prefill_dma_kerne
       const uint32_t* w1 = (const uint32_t*)&v1;
       const u32x4 vf = {w0[0], w0[1], w1[0], w1[1]};
 #pragma unroll
-      for (int u = 0; u < QG; ++u) accO[u][dt] = mfma16<T>(vf, pf[u], accO[u][dt]);
+      for (int u = 0; u < QG; ++u) {
+        accO[u][dt] = mfma16<T>(vf, pf[u], accO[u][dt]);
+        accO[u][dt] = mfma16<T>(vf, pl[u], accO[u][dt]);
+      }
     }
     // lgkmcnt(0): every LDS read of this iteration has RETURNED before the barrier lets another wave issue the DMA that
     // overwrites this buffer's predecessor -- hipcc may sink an MFMA, and the wait in front of it, below the barrier, and

@@ -58,6 +58,33 @@ def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
 ACCUM_MODES = ("exact", "f32_seq32", "f32_pairwise")
 ACCUM = "exact"
 CHUNK = 32
+# A third variant (round 4), orthogonal to the order: SDPA_P16 rounds the softmax numerators exp(s - max) to the KV dtype
+# before P.V while the denominator sums the unrounded float32 values -- what a 16-bit matrix-core attention kernel does
+# when it feeds P to the MFMA as 16-bit operands (the reference's kernel keeps P in float32, App. A.4).  Used to attribute
+# the device's excess over the two float32 orders in the model-dtype KV mode.
+SDPA_P16 = False
+
+
+def set_sdpa_p16(on: bool) -> None:
+    global SDPA_P16
+    SDPA_P16 = bool(on)
+
+
+# A fourth variant (round 4, an experiment recorded in DESIGN 8): X_SPLIT2 rounds FLOAT32 activations entering a 16-bit or
+# quantised linear to two 16-bit terms (hi = T(x), lo = T(x - hi): ~17 mantissa bits) when the call has more than 16 rows --
+# what a two-pass matrix-core prefill GEMM would compute instead of the three-term (exact) split.
+X_SPLIT2 = False
+
+
+def set_x_split2(on: bool) -> None:
+    global X_SPLIT2
+    X_SPLIT2 = bool(on)
+
+
+def split2(x: np.ndarray, dtype: str) -> np.ndarray:
+    hi = round_to(x.astype(np.float32), dtype)
+    lo = round_to((x.astype(np.float32) - hi).astype(np.float32), dtype)
+    return (hi + lo).astype(np.float32)
 
 
 def set_accum(mode: str) -> None:

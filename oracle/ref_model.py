@@ -92,6 +92,8 @@ class Linear:
     def __call__(self, x: np.ndarray, xdt: str):
         """x @ W.T with fp32 accumulation; output dtype = result_type(x, W) (App. A.1)."""
         odt = promote(xdt, self.dtype)
+        if numerics.X_SPLIT2 and xdt == "float32" and self.dtype != "float32" and x.size // x.shape[-1] > 16:
+            x = numerics.split2(x, self.dtype)
         y = round_to(self._matmul(x), odt)
         if self.lora_a is not None:
             # y + (scale * ((x @ A) @ B)).astype(x.dtype)     (App. A.6)
@@ -259,7 +261,8 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     rep = Hq // Hkv
     odt = promote(qdt, kdt)
     if numerics.ACCUM != "exact":
-        return round_to(_sdpa_f32(q, k, v, scale, mask, numerics.ACCUM), odt), odt
+        p16 = kdt if (numerics.SDPA_P16 and kdt != "float32") else None
+        return round_to(_sdpa_f32(q, k, v, scale, mask, numerics.ACCUM, p16), odt), odt
     k = np.repeat(k, rep, axis=1).astype(np.float64)
     v = np.repeat(v, rep, axis=1).astype(np.float64)
     s = np.matmul(q.astype(np.float64), k.transpose(0, 1, 3, 2)) * float(scale)     # (B,H,L,S), float64 sums
@@ -272,7 +275,7 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     return round_to(o, odt), odt
 
 
-def _sdpa_f32(q, k, v, scale, mask, mode):
+def _sdpa_f32(q, k, v, scale, mask, mode, p16=None):
     """The same attention with float32 accumulators (accumulation envelope, numerics.set_accum): scores = chunks of 32
     head-dim products, softmax in float32 (max, exp, sum over chunks of 32 keys), P.V over chunks of 32 keys; per
     (row, kv head) to bound memory.  Output float32 values, rounded to the output dtype by the caller."""
@@ -294,6 +297,8 @@ def _sdpa_f32(q, k, v, scale, mask, mode):
             s = s - s.max(axis=-1, keepdims=True)
             p = np.exp(s.astype(np.float32)).astype(np.float32)
             den = numerics.sum_last_f32(p, mode)[..., None]
+            if p16 is not None:                                            # numerics.SDPA_P16: 16-bit P operands, float32 sum
+                p = round_to(p, p16)
             a = numerics.Accum(mode)
             for s0 in range(0, S, CH):
                 a.add(np.matmul(p[..., s0:s0 + CH].astype(np.float64), vv[s0:s0 + CH].astype(np.float64)).astype(np.float32))

@@ -181,7 +181,10 @@ def teacher_forced(ref, cfg, case, g, want_full=()):
     return np.stack(lp_tok), np.stack(lp_top), np.stack(amax), full
 
 
-def run_envelope(ref, cfg, ck, case):
+def run_envelope(ref, cfg, ck, case, p16=False, x2=False):
+    """p16 (round 4, `--envelope --p16`): the two orders again with the softmax numerators rounded to the KV dtype before P.V
+    (numerics.SDPA_P16 -- a 16-bit matrix-core attention), ADDED to the case's committed envelope file as
+    f32_seq32_p16 / f32_pairwise_p16; only meaningful for the model-dtype KV cases."""
     from oracle import numerics
 
     path = OUT / f"{case['name']}.npz"
@@ -192,17 +195,27 @@ def run_envelope(ref, cfg, ck, case):
     t0 = time.time()
     for mode in ("f32_seq32", "f32_pairwise"):
         numerics.set_accum(mode)
+        numerics.set_sdpa_p16(p16)
+        numerics.set_x_split2(x2)
         try:
-            res[mode] = teacher_forced(ref, cfg, case, g)
+            res[mode + ("_p16" if p16 else "") + ("_x2" if x2 else "")] = teacher_forced(ref, cfg, case, g)
         finally:
             numerics.set_accum("exact")
-        print(f"  {case['name']} {mode}: {time.time() - t0:.0f} s", flush=True)
+            numerics.set_sdpa_p16(False)
+            numerics.set_x_split2(False)
+        print(f"  {case['name']} {mode}{' p16' if p16 else ''}: {time.time() - t0:.0f} s", flush=True)
     # exact reference values for the same quantities: chosen-token logprob is stored; top-8 logprobs = top_vals - logZ, with
     # logZ recovered from the greedy rows (token = top-1) or re-derived from the variants' own gap (sampled rows: see below)
     lp_exact = g["logprobs"].astype(np.float64)
     greedy = case["temp"] == 0.0
-    out = dict(spec=str(g["spec"]))
-    summ = dict(case=case["name"], steps=steps, B=B)
+    epath = OUT / "envelope" / f"{case['name']}.npz"
+    if p16 or x2:
+        prev = np.load(epath)
+        out = {k: prev[k] for k in prev.files}
+        summ = json.loads(str(prev["summary"]))
+    else:
+        out = dict(spec=str(g["spec"]))
+        summ = dict(case=case["name"], steps=steps, B=B)
     for mode, (lp_tok, lp_top, amax, _f) in res.items():
         d = np.abs(lp_tok - lp_exact)
         summ[mode] = dict(max_lp=float(d.max()), mean_lp=float(d.mean()),
@@ -214,13 +227,14 @@ def run_envelope(ref, cfg, ck, case):
         out[f"lp_{mode}"] = lp_tok.astype(np.float32)
         out[f"top_lp_{mode}"] = lp_top.astype(np.float32)
         out[f"argmax_{mode}"] = amax.astype(np.int32)
-    a, b = res["f32_seq32"], res["f32_pairwise"]
-    summ["seq32_vs_pairwise"] = dict(max_lp=float(np.abs(a[0] - b[0]).max()), mean_lp=float(np.abs(a[0] - b[0]).mean()),
-                                     max_top8_lp=float(np.abs(a[1] - b[1]).max()), id_diffs=int((a[2] != b[2]).sum()))
-    summ["oracle_margins_le_1e-2"] = int((g["margins"] <= 1e-2).sum())
+    if not (p16 or x2):
+        a, b = res["f32_seq32"], res["f32_pairwise"]
+        summ["seq32_vs_pairwise"] = dict(max_lp=float(np.abs(a[0] - b[0]).max()), mean_lp=float(np.abs(a[0] - b[0]).mean()),
+                                         max_top8_lp=float(np.abs(a[1] - b[1]).max()), id_diffs=int((a[2] != b[2]).sum()))
+        summ["oracle_margins_le_1e-2"] = int((g["margins"] <= 1e-2).sum())
     out["summary"] = json.dumps(summ)
     (OUT / "envelope").mkdir(exist_ok=True)
-    np.savez_compressed(OUT / "envelope" / f"{case['name']}.npz", **out)
+    np.savez_compressed(epath, **out)
     print(f"envelope {json.dumps(summ)}", flush=True)
 
 
@@ -235,7 +249,7 @@ def run_full_logits(ref, cfg, ck, case):
 
 def main():
     args = sys.argv[1:]
-    envelope, logits = "--envelope" in args, "--logits" in args
+    envelope, logits, p16, x2 = "--envelope" in args, "--logits" in args, "--p16" in args, "--x2" in args
     only = set(a for a in args if not a.startswith("--"))
     if envelope or logits:
         for ck, cases in CHECKPOINTS.items():
@@ -257,7 +271,8 @@ def main():
                         run_full_logits(ref, cfg, ck, case)
                         ref_model.CACHE_F64 = False
                     if envelope:
-                        run_envelope(ref, cfg, ck, case)
+                        if (not p16 or not case["paged"]) and (not x2 or case["paged"]):
+                            run_envelope(ref, cfg, ck, case, p16, x2)
         return
     ref_model.CACHE_F64 = True
     for ck, cases in CHECKPOINTS.items():

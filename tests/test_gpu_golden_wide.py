@@ -45,6 +45,11 @@ SERVING = sorted(GOLD.glob("serving_*.npz"))
 # (max and mean of |logprob - exact|, the same for the 8 largest logits), and may flip at most that many more greedy ids
 # than the worse variant did.  The absolute ceilings stay as a backstop.
 ENVELOPE_FACTOR = 1.5
+# The MEAN is the statistically tight quantity (616 samples per 2-block case).  Round 3 measured the device's mean at
+# 1.05 - 1.33 x the envelope's in every 16-bit-KV case; round 4 found the rounding that did it -- P fed to the matrix core
+# as ONE 16-bit operand; the CPU variant with that rounding (envelope keys f32_*_p16) shows the same excess -- and removed it
+# (attn_decode.hip pack2_split): the device now measures 0.88 - 1.02 x the larger variant's mean, and the bound is 1.15 x.
+MEAN_FACTOR = 1.15
 EXACT_MARGIN, EXACT_LP, EXACT_LP_MEAN = 1e-2, 2e-2, 1e-3
 MODELKV_MARGIN, MODELKV_LP = 0.13, 0.1
 
@@ -206,11 +211,14 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
         assert lp_err <= max(f * E, E + 1.05 * quantum), (path.stem, "max |logprob - exact|", lp_err, env, quantum)
         # how many samples may lie beyond the envelope's worst: the CPU variants themselves show such two-quantum samples
         # in 0.05 .. 0.5 % of a case's chosen tokens (5 of ~9000 over the nine 16-bit cases), and the device's float32 sums
-        # (matrix-core dot products of 32 terms + split-K partial sums) are not IEEE-sequential -- its MEAN error runs
-        # 0.97 .. 1.33 x the envelope's (bounded at 1.5 x below); 2 % caps the tail without making it a coin toss
+        # (matrix-core dot products of 32 terms + split-K partial sums) are not IEEE-sequential; 2 % caps the tail without
+        # making it a coin toss (the mean is bounded at MEAN_FACTOR x the envelope's below)
         over = int(np.sum(np.asarray(lp_all) > f * E))
         assert over <= max(2, len(lp_all) // 50), (path.stem, "samples beyond the envelope", over, len(lp_all), env)
-        assert lp_sum / max(lp_n, 1) <= f * env["mean_lp"], (path.stem, "mean |logprob - exact|", lp_sum / max(lp_n, 1), env)
+        # (full-depth cases hold 32 samples, and a 32-sample mean is not a tight statistic: the two CPU variants' own means
+        # differ by up to 2.3 x there -- 2.6e-4 against 1.1e-4 on wide_qwen3_int4_full_paged -- so they keep the 1.5)
+        mf = MEAN_FACTOR if layers == wide_models.LAYERS else ENVELOPE_FACTOR
+        assert lp_sum / max(lp_n, 1) <= mf * env["mean_lp"], (path.stem, "mean |logprob - exact|", lp_sum / max(lp_n, 1), env)
         if greedy:
             assert top_err <= max(f * E, E + 1.05 * quantum), (path.stem, "top-8 logprobs", top_err, env, quantum)
             # (every flip was checked against the envelope's flip margin where it happened; the count is bounded by how many

@@ -411,6 +411,63 @@ def test_sampler_greedy_logprobs_topk(V):
         assert np.allclose(kl[b], lsm[b, order], atol=1e-4)
 
 
+def _oracle_candidates(lg_row, temp, top_p):
+    """The oracle's candidate list in draw order (descending probability, ties by ascending id) with float64 masses."""
+    if top_p < 1.0:
+        ids, pr = ref_sample.top_p_candidates(lg_row, top_p, temp)
+        return np.asarray(ids), np.asarray(pr, dtype=np.float64)
+    x = lg_row.astype(np.float64) / float(temp)
+    p = np.exp(x - x.max())
+    ids = np.lexsort((np.arange(len(p)), -p))
+    return ids, p[ids]
+
+
+def _nucleus_cut_slack(lg_row, temp, top_p, n):
+    """The nucleus itself is cut at top_p * Z: if the full distribution's cumulative at the cut lies within the same
+    arithmetic's worst-case error (+ the float32 top_p) of top_p, the device may keep one candidate more or fewer, which
+    renormalises every edge by that candidate's share.  -> that share (0.0 when the cut is not that close)."""
+    if top_p >= 1.0:
+        return 0.0
+    xs = lg_row.astype(np.float64) / float(temp)
+    pf = np.exp(xs - xs.max())
+    order = np.lexsort((np.arange(len(pf)), -pf))
+    pf = pf[order] / pf.sum()
+    cf = np.cumsum(pf)
+    ef = (5.5 * np.abs(np.log(np.maximum(pf / pf[0], 1e-300))) + 2.0) * 2.0 ** -24
+    slack = float(np.sum(pf * ef)) + abs(float(np.float32(top_p)) - top_p) + (len(pf) + 1) * 2.0 ** -40
+    near = [k for k in (n - 2, n - 1) if 0 <= k < len(cf) and abs(cf[k] - top_p) <= slack]
+    if not near:
+        return 0.0
+    return float(pf[min(n, len(pf) - 1)] / cf[n - 1]) + float(pf[n - 1] / cf[n - 1])
+
+
+def _sampler_edge_bound(lg_row, temp, top_p, ids, pr, j, u):
+    """How far the device's boundary between candidates j and j + 1 may lie from the oracle's cumulative c_j (DESIGN 2,
+    "sampler boundary bound"), from the kernel's arithmetic (misc.hip mass_fx / sample_kernel):
+      * candidate i has the mass floor(2^40 * __expf((l_i - max) * (1/T))), __expf(a) = v_exp_f32(a * log2(e)).  The
+        float32 roundings on the ARGUMENT -- l - max, 1/T, the product, log2(e), that product; T itself is a float32 on the
+        device and a double in the oracle -- are 5.5 half-ulps = 5.5 * 2^-24 relative, i.e. a RELATIVE mass error of
+        |a_i| * 5.5 * 2^-24 (a_i in nats), plus one ulp (2^-23) of v_exp_f32: eps_i = (5.5 |a_i| + 2) 2^-24;
+      * c'_j - c_j = ((1 - c_j) sum_{i<=j} p_i e_i - c_j sum_{i>j} p_i e_i) / (1 + sum p_i e_i), |e_i| <= eps_i: the
+        worst case puts every rounding below the edge one way and every one above it the other way;
+      * truncation to 2^-40 fixed point: at most one unit per candidate and one for u * Z, against Z >= 2^40 (the
+        largest mass is exactly 2^40);
+      * u reaches the device as a float32: half an ulp of u.
+    A function of the candidates' masses, the cumulative position and their number -- ~1e-7 for these rows; the measured
+    edges (tools/debug/sampler_edge_probe.py, 136 boundaries) lie within 3.6e-8, i.e. the float32 u alone."""
+    x = lg_row.astype(np.float64)
+    a = np.abs((x[ids] - x.max()) / float(temp))
+    p = np.asarray(pr, np.float64) / np.sum(pr)
+    eps = (5.5 * a + 2.0) * 2.0 ** -24
+    c = float(np.cumsum(p)[j])
+    below, above = float(np.sum((p * eps)[: j + 1])), float(np.sum((p * eps)[j + 1:]))
+    mass = ((1.0 - c) * below + c * above) / (1.0 - below - above)
+    bound = mass + (len(ids) + 1) * 2.0 ** -40 + 0.5 * float(np.spacing(np.float32(u)))
+    share = _nucleus_cut_slack(lg_row, temp, top_p, len(ids))
+    return bound + share
+    return bound
+
+
 @pytest.mark.parametrize("V", [64, 5000, 32000, 151936])
 @pytest.mark.parametrize("temp,top_p", [(1.0, 0.9), (0.7, 0.5), (1.3, 1.0), (1.0, 0.05)])
 def test_sampler_top_p_injected_uniforms(V, temp, top_p):
@@ -433,16 +490,55 @@ def test_sampler_top_p_injected_uniforms(V, temp, top_p):
         if toks[b] != want["tokens"][b, 0]:
             # The draw is u against a cumulative distribution; the device sums 2^-40 fixed-point masses of __expf, the
             # oracle float64 probabilities.  They may only disagree when u falls within that arithmetic's error of a
-            # boundary between two neighbouring candidates.
-            ids, pr = (ref_sample.top_p_candidates(lg[b], top_p, temp) if top_p < 1.0 else
-                       (lambda x: (np.argsort(-x, kind="stable"), np.sort(x)[::-1]))(
-                           np.exp((lg[b].astype(np.float64) - lg[b].max()) / temp) / np.exp((lg[b].astype(np.float64) - lg[b].max()) / temp).sum()))
-            ids, cum = np.asarray(ids), np.cumsum(np.asarray(pr, dtype=np.float64) / np.sum(pr))
+            # boundary between two neighbouring candidates: the DERIVED bound of _sampler_edge_bound.
+            ids, pr = _oracle_candidates(lg[b], temp, top_p)
+            cum = np.cumsum(pr / np.sum(pr))
             rw, rg = int(np.where(ids == want["tokens"][b, 0])[0][0]), int(np.where(ids == toks[b])[0][0])
-            edge = cum[min(rw, rg)]
-            # (the exponent's argument (x - max) / T * log2(e) reaches ~16 in float32: one rounding there is 1e-6 of a
-            # mass, and every mass below the edge carries a few of them -- seen: 3.2e-6 at a cumulative 0.70)
-            assert abs(rw - rg) == 1 and abs(float(u[b]) - edge) <= 8e-6, (b, rw, rg, float(u[b]), edge)
+            j = min(rw, rg)
+            bound = _sampler_edge_bound(lg[b], temp, top_p, ids, pr, j, float(u[b]))
+            assert abs(rw - rg) == 1 and abs(float(u[b]) - cum[j]) <= bound, (b, rw, rg, float(u[b]), cum[j], bound)
             mism += 1
     assert mism <= 1, (toks, want["tokens"][:, 0])
     assert np.allclose(lp, want["log_softmax"][np.arange(B), toks], atol=1e-4)
+
+
+@pytest.mark.parametrize("V,std,bf", [(5000, 3.0, False), (32000, 1.3, True), (151936, 3.0, False)])
+@pytest.mark.parametrize("temp,top_p", [(1.0, 0.9), (0.7, 0.5), (1.3, 1.0), (1.0, 0.05)])
+def test_sampler_edges_within_derived_bound(V, std, bf, temp, top_p):
+    """The derived boundary bound, exercised on every run: for boundaries spread over each row's candidate list, a
+    uniform placed just beyond (before) the oracle's cumulative edge by the bound must draw the candidate after (before)
+    the edge.  One launch: 8 boundaries x 2 sides x 4 logits rows."""
+    rng = np.random.default_rng(977 + V + int(100 * temp))
+    rows, us, wants = [], [], []
+    for _ in range(4):
+        for _try in range(50):                     # rows whose nucleus cut is ambiguous (see _nucleus_cut_slack) are redrawn
+            lg = (rng.standard_normal(V) * std).astype(np.float32)
+            if bf:
+                lg = round_to(lg, "bfloat16")
+            ids, pr = _oracle_candidates(lg, temp, top_p)
+            if _nucleus_cut_slack(lg, temp, top_p, len(ids)) == 0.0:
+                break
+        else:
+            pytest.fail("no row with an unambiguous nucleus cut in 50 draws")
+        cum = np.cumsum(pr / np.sum(pr))
+        n = len(ids)
+        if n < 2:
+            continue
+        pn = pr / np.sum(pr)
+        for q in (0.0, 0.05, 0.15, 0.3, 0.5, 0.7, 0.9, 0.98):         # cumulative positions (q = 0: the first boundary)
+            j = min(int(np.searchsorted(cum, q)), n - 2)
+            if j < 0:
+                continue
+            bound = _sampler_edge_bound(lg, temp, top_p, ids, pr, j, float(cum[j]))
+            assert bound < 2e-6, (V, temp, top_p, j, bound)            # the derivation is not a licence: rows like these give ~1e-7
+            if min(pn[j], pn[j + 1]) <= 2.0 * bound:                   # a candidate narrower than the bound cannot be targeted
+                continue
+            for side, want in ((-1.0, ids[j]), (+1.0, ids[j + 1])):
+                uu = float(cum[j]) + side * bound
+                if 0.0 <= uu < 1.0:
+                    rows.append(lg), us.append(uu), wants.append(int(want))
+    if not us:
+        pytest.skip("every row's nucleus is a single candidate")
+    toks, _lp, _p0, _, _ = _run_sampler(np.stack(rows), temp, top_p, np.asarray(us))
+    bad = [(i, us[i], int(toks[i]), wants[i]) for i in range(len(us)) if int(toks[i]) != wants[i]]
+    assert not bad, bad[:5]
