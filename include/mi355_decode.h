@@ -234,6 +234,9 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  *                             staging of the next (default 1)
  *   "defer_norm"              0: float32-activation (PagedKVCache mode) decode steps run the RMSNorm as its own launch
  *                             instead of applying its row scale in the epilogue of the linear behind it (default 1)
+ *   "prefill_x_terms"         3: float32-activation (PagedKVCache mode) prefill multiplies an EXACT three-term 16-bit split of x
+ *                             by dense bf16 weights (three walks of W); default 2: hi + lo, 16+ mantissa bits of x, two walks
+ *                             (the CPU float32-accumulating variants do not move under it: DESIGN 8d); int4 always 3
  *   "short_prefill_skinny"    0: prefill calls of <= 128 rows in all through the tile GEMM like longer ones (default 1: the
  *                             weight-streaming split-K kernel of the decode steps, ~2x faster at that size)
  *   "tile_weights"            0: keep weights row-major (before mi_engine_finalize only; default 1)

@@ -117,6 +117,7 @@ struct mi_engine {
   // RMSNorm hand-over between gemm_skinny launches (GemvCall::sq_out / sq_in): the residual linear in front of a norm
   // leaves the rows' sums of squares, the normalised linear behind it uses them instead of an rmsnorm launch
   int opt_norm_handover = 1;    // round 2 (partial sums read in ONE round trip): Mistral-7B int4 +3.2 %, int8 +2.9 %, bf16 B = 16 +3.7 %, Qwen3-14B int4 +0.6 %
+  int opt_prefill_x_terms = 2;  // float32 activations, prefill tile GEMM on dense bf16 weights: 16-bit terms of x (2 or 3 = exact)
   int opt_defer_norm = 1;       // float32 activations: RMSNorm row scale applied in the split-K kernel's epilogue (no norm launch)
   int opt_short_prefill_skinny = 1;   // short prefill / mixed calls on the weight-streaming kernel instead of the tile GEMM (gemv_rows)
   float* d_sq = nullptr;        // [4096 tile groups][16 rows]
@@ -506,8 +507,11 @@ int gemv_rows_on(mi_engine* e, const FusedLinear& f, const FusedLinear& f0, Gemv
         MI_HIP(hipMalloc(&e->xs, need));
         e->xs_cap = need;
       }
-      MI_TRY(launch_split3_rows(c.x, c.ldx, c.pro == PRO_NORM ? c.norm_w : nullptr, c.eps, e->xs, (int)rows, KT, e->stream));
-      c.x = e->xs; c.ldx = 3 * KT; c.pro = PRO_NONE;
+      // dense bf16 weights: two terms (16+ mantissa bits of x, two walks of W; option "prefill_x_terms"); int4 / [hi | lo]
+      // matrices keep the exact three (their own pair needs the 3 : 2 walk)
+      const int terms = (e->opt_prefill_x_terms == 2 && f.W.wk == WK_BF16 && c.kx == 0 && c.rnd == RND_NONE) ? 2 : 3;
+      MI_TRY(launch_split3_rows(c.x, c.ldx, c.pro == PRO_NORM ? c.norm_w : nullptr, c.eps, e->xs, (int)rows, KT, e->stream, terms));
+      c.x = e->xs; c.ldx = terms * KT; c.pro = PRO_NONE;
     } else if (c.pro == PRO_NORM) {    // (one workgroup per row also here: one L2 round trip per row instead of a wave's 16)
       MI_TRY(launch_rmsnorm_rows(c.x, c.ldx, c.norm_w, e->xn, KT, (int)rows, KT, c.eps, c.act, e->stream, true));
       c.x = e->xn; c.ldx = KT; c.pro = PRO_NONE;
@@ -1745,6 +1749,7 @@ int mi_engine_set_option(mi_engine* e, const char* key, int64_t value) {
   if (k == "skinny_gemm") { e->opt_skinny_gemm = value != 0; return MI_OK; }
   if (k == "norm_handover") { e->opt_norm_handover = value != 0; return MI_OK; }
   if (k == "defer_norm") { e->opt_defer_norm = value != 0; return MI_OK; }
+  if (k == "prefill_x_terms") { if (value != 2 && value != 3) return fail(MI_ERR_INVALID, "prefill_x_terms: 2 or 3"); e->opt_prefill_x_terms = (int)value; return MI_OK; }
   if (k == "short_prefill_skinny") { e->opt_short_prefill_skinny = value != 0; return MI_OK; }
   if (k == "decode_attention_mfma") { e->opt_attn_mfma = value != 0; return MI_OK; }
   if (k == "fused_gemv_pairs") { e->opt_fused_pairs = (int)value; return MI_OK; }

@@ -988,9 +988,12 @@ __global__ __launch_bounds__(256) void rmsnorm_row_block_f32_kernel(const float*
 // mantissa bits), stored side by side as one row [hi | mid | lo] of 3 K elements.  The GEMM then walks W three times
 // (GemmParams::kw): every product is exact in the float32 accumulator, so the result is a float32 dot product in
 // another summation order -- the same arithmetic as the decode step's skinny_kernel<.., X32>.  One workgroup per row.
+// terms = 2 (round 4, dense bf16 weights): [hi | lo] only, 16+ mantissa bits of x, TWO walks of W instead of three.  What
+// that costs in accuracy was measured on the CPU before it was built (oracle/numerics.py X_SPLIT2): the
+// float32-accumulating variants' deviation from the exact oracle does not move (mean 1.91352e-4 vs 1.91362e-4).
 template <typename AT>
 __global__ __launch_bounds__(256) void split3_rows_kernel(const float* x, int ldx, const float* norm_w, float eps, AT* out,
-                                                          int K) {
+                                                          int K, int terms) {
   __shared__ float part[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (size_t)row * ldx;
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* x, int ld
     __syncthreads();
     rs = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)K + eps);
   }
-  AT* o = out + (size_t)row * 3 * K;
+  AT* o = out + (size_t)row * terms * K;
   for (int k = tid * 4; k < K; k += 1024) {
     f32x4 v = *(const f32x4*)(xr + k);
     if (norm_w != nullptr) {
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* x, int ld
     }
     *(uint2*)(o + k) = *(const uint2*)hi;
     *(uint2*)(o + K + k) = *(const uint2*)mid;
-    *(uint2*)(o + 2 * K + k) = *(const uint2*)lo;
+    if (terms == 3) *(uint2*)(o + 2 * K + k) = *(const uint2*)lo;      // (uniform)
   }
 }
 
@@ -1093,10 +1096,12 @@ int launch_rmsnorm_rows(const void* x, int ldx, const void* w, void* out, int ld
 // int4 weights: `scratch` (>= dequant_hilo_bytes(N, K)) receives the [hi | lo] copy first.
 size_t split3_bytes(size_t rows, int K) { return rows * 3 * (size_t)K * 2; }
 
-int launch_split3_rows(const void* x, int ldx, const void* norm_w, float eps, void* out, int rows, int K, hipStream_t st) {
+int launch_split3_rows(const void* x, int ldx, const void* norm_w, float eps, void* out, int rows, int K, hipStream_t st,
+                       int terms) {
   if (K % 4 != 0 || ldx % 4 != 0) return fail(MI_ERR_UNSUPPORTED, "split3_rows: K and the row stride must be multiples of 4");
+  if (terms != 2 && terms != 3) return fail(MI_ERR_INVALID, "split3_rows: two or three terms");
   hipLaunchKernelGGL(split3_rows_kernel<bf16>, dim3(rows), dim3(256), 0, st, (const float*)x, ldx, (const float*)norm_w, eps,
-                     (bf16*)out, K);
+                     (bf16*)out, K, terms);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -1119,8 +1124,11 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
     const bool hilo = c.kx > 0 && !wk_is_quant(W.wk);
     const int kt = hilo ? c.kx : W.K;      // the true K
     if (hilo && (W.K != 2 * c.kx || W.wk != WK_BF16)) return fail(MI_ERR_INVALID, "gemm_prefill: a [hi | lo] matrix has 2 kx bf16 columns");
-    if (c.ldx != 3 * kt) return fail(MI_ERR_INVALID, "gemm_prefill: float32 activations must be split first (launch_split3_rows)");
-    p.ka = 3 * kt; p.K = ((wk_is_quant(W.wk) || hilo) ? 6 : 3) * kt; p.out32 = 1;
+    const bool pair = wk_is_quant(W.wk) || hilo;     // W itself is a [hi | lo] pair: 3 x-terms against 2 W-terms meet over 6 kt steps
+    const int terms = c.ldx == 2 * kt ? 2 : 3;
+    if (c.ldx != terms * kt || (pair && terms != 3))
+      return fail(MI_ERR_INVALID, "gemm_prefill: float32 activations must be split first (launch_split3_rows; two terms: dense bf16 weights only)");
+    p.ka = terms * kt; p.K = (pair ? 6 : terms) * kt; p.out32 = 1;
     if (hilo) p.kw = 2 * kt;
   }
   p.epi = c.epi; p.out = c.out; p.ldo = c.ldo; p.resid = c.resid; p.pair_offset = c.pair_offset;

@@ -86,7 +86,8 @@ int launch_gemm_prefill(const LinearW& W, const GemvCall& c, size_t rows, hipStr
 // float32 activations (PagedKVCache mode) in front of launch_gemm_prefill: rows of [hi | mid | lo] bf16, 3 K wide, with the
 // RMSNorm (norm_w = float32 weights, or null) applied first; then call launch_gemm_prefill with c.x = out, c.ldx = 3 K
 size_t split3_bytes(size_t rows, int K);
-int launch_split3_rows(const void* x, int ldx, const void* norm_w, float eps, void* out, int rows, int K, hipStream_t st);
+int launch_split3_rows(const void* x, int ldx, const void* norm_w, float eps, void* out, int rows, int K, hipStream_t st,
+                       int terms = 3);
 // int4 (tile-major) -> 16-bit tile-major [hi | lo], K' = 2K: the operand of the prefill GEMM for quantised weights
 size_t dequant_hilo_bytes(int N, int K);
 int launch_dequant_q4_hilo(const LinearW& src, void* dst, hipStream_t st);
