@@ -537,6 +537,8 @@ int gemv_cu_count();
 // 218 workgroups, ONE round on 256 CUs where 4 x 2 gives 272 = two rounds (85); lm_head 2 row tiles 254 (272); the narrow
 // linears stay on the split-K kernel (q|k|v 24.5 vs 23.4, o 24.1 vs 21.2, down 53 vs 37.5: 80-112 tile groups leave this
 // shape ~10 chunks per workgroup around a 2.5 us head and tail) -- gemm_q4_supported() routes only the wide ones here.
+static int q4_min_tiles() { static const int v = q4_env("MI_Q4_MIN_TILES", 1024); return v; }
+
 static Q4Plan q4_plan(const LinearW& W, const GemvCall& c, size_t rows) {
   Q4Plan pl{};
   const bool sw = c.epi == EPI_SWIGLU;
@@ -556,6 +558,9 @@ static Q4Plan q4_plan(const LinearW& W, const GemvCall& c, size_t rows) {
     pl.mt = std::min(mt_all, sw ? 4 : 2);
     pl.nslab = (mt_all + pl.mt - 1) / pl.mt;
     pl.TW = 5; pl.KW = 2; pl.NS = 2; pl.ksplit = 1;
+    // a narrow matrix behind an RMSNorm (q|k|v): few tile pairs, so two per workgroup and K over four waves (sweep on
+    // 7168 x 5120 at 64 rows: 20 us + the 4.5-us preparation pass that is ALSO the norm, against 23.4 + 4.7)
+    if (!sw && pl.ntiles < q4_min_tiles()) { pl.TW = 2; pl.KW = 4; pl.NS = 4; }
     pl.ngroups = (pl.ntu + pl.TW - 1) / pl.TW;
     best = 0.0;
   }
@@ -610,9 +615,12 @@ bool gemm_q4_supported(const LinearW& W, const GemvCall& c, size_t rows) {
   if (n % 16 != 0) return false;
   if (c.epi == EPI_SWIGLU_GU8) return false;
   // wide matrices only (gate|up, lm_head: >= 1024 tiles), unless a plan is forced (tests, A/B): see q4_plan
-  static const int min_tiles = q4_env("MI_Q4_MIN_TILES", 1024);
+  // ... and, behind MI_Q4_NARROW=1 (A/B), the narrow matrix that has an RMSNorm in front (q|k|v), where the preparation pass
+  // replaces the norm launch: measured on the config-5 shard 7301 / 7309 tok/s against 7345 / 7342 without (same box,
+  // alternating) -- not taken
+  static const int narrow = q4_env("MI_Q4_NARROW", 0);
   const bool forced = q4_force_mt > 0 || q4_force_tw > 0 || q4_force_kw > 0 || q4_force_ks > 0 || q4_force_ns > 0;
-  if (!forced && W.N / 16 < min_tiles) return false;
+  if (!forced && W.N / 16 < q4_min_tiles() && !(narrow && c.pro == PRO_NORM && W.N / 16 >= 256 && rows > 32)) return false;
   return true;
 }
 
