@@ -633,11 +633,204 @@ __global__ __launch_bounds__(G * 64, 2) void attn_prefill_f32_kernel(AttnCall c)
   }
 }
 
+// The same launch on the bf16 matrix core with SPLIT OPERANDS (round 4; the default for this mode): q, K, P and V are each
+// two bf16 terms, x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16+ mantissa bits), and every product is three MFMAs --
+// hi.hi + hi.lo + lo.hi (the lo.lo term is 2^-16 of the product) -- of v_mfma_f32_16x16x32_bf16: 48 MFMAs of 16 cycles per
+// 32 keys against 128 of 32 cycles on v_mfma_f32_16x16x4_f32.  Workgroup shape, block size, LDS image layouts, masking and
+// the online softmax are those of attn_prefill_kernel<bf16> (blocks of 32 keys, one query group per wave); K / V are read
+// from the float32 caches and split while they are written to LDS (each element once per workgroup, not once per wave).
+// What the 16+ bits cost was looked at on the CPU first (oracle/numerics.py SDPA_SPLIT2: the float32-accumulating
+// variants do not move).  MI_ATTN_PREFILL_F32_EXACT=1 (read per call) runs attn_prefill_f32_kernel instead.
+template <int D, int G, bool PAGED>
+__global__ __launch_bounds__(G * 64, 2) void attn_prefill_f32s_kernel(AttnCall c) {
+  static_assert(D % 32 == 0 && D <= 128, "head_dim 32..128");
+  using T = bf16;
+  constexpr int KK = D / 32, DT = D / 16, NT = G * 64;
+  constexpr int NPIECE = KB * D / 4;                  // 16-byte pieces (4 floats) of one K (or V) block
+  constexpr int NP = (NPIECE + NT - 1) / NT;          // per thread
+  constexpr int IMG = KB * D * 2;                     // bytes of one 16-bit image
+  constexpr float LOG2E = 1.4426950408889634f;
+  const AttnShape& s = c.s;
+  const int qt = gridDim.x - 1 - blockIdx.x, bh = blockIdx.y;
+  const int b = bh / s.Hkv, kh = bh % s.Hkv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = s.rows ? s.rows[b] : b;              // cache row of batch entry b
+  const int off = c.offsets[kb];
+  const int t0 = qt * QT;
+  const int nk = off + min(t0 + QT, s.L);             // keys any query of the tile may see
+  const int nb = (nk + KB - 1) / KB;
+  const int h = kh * G + wave;
+
+  __shared__ __attribute__((aligned(16))) unsigned char khi[2][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char klo[2][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char vhi[2][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char vlo[2][IMG];
+
+  const float* kc = (const float*)c.kcache;
+  const float* vc = (const float*)c.vcache;
+
+  f32x4 kreg[NP], vreg[NP];
+  auto load_block = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = min(i * NT + tid, NPIECE - 1);
+      const int key = min(j * KB + piece / (D / 4), nk - 1), dc = piece % (D / 4);
+      const size_t ro = kv_elem<PAGED>(s, kb, kh, key) + 4 * dc;
+      kreg[i] = *(const f32x4*)(kc + ro);
+      vreg[i] = *(const f32x4*)(vc + ro);
+    }
+  };
+  auto split4 = [](const f32x4& v, u32x2& hi, u32x2& lo) {
+    uint32_t h0, l0, h1, l1;
+    pack2_split<T>(v.x, v.y, h0, l0);
+    pack2_split<T>(v.z, v.w, h1, l1);
+    hi = u32x2{h0, h1};
+    lo = u32x2{l0, l1};
+  };
+  auto store_block = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = i * NT + tid;
+      if (piece < NPIECE) {
+        const int key = piece / (D / 4), dc4 = piece % (D / 4), dc = dc4 >> 1, half = (dc4 & 1) * 8;   // dc: the 8-element piece of the 16-bit images
+        u32x2 hi, lo;
+        split4(kreg[i], hi, lo);
+        // K: [16-key tile][kk][g][key & 15] x 16 B -- a fragment read of (tile, kk) is 1 KiB contiguous
+        const size_t ka = (size_t)((((key >> 4) * KK + (dc >> 2)) * 4 + (dc & 3)) * 16 + (key & 15)) * 16 + half;
+        *(u32x2*)(khi[buf] + ka) = hi;
+        *(u32x2*)(klo[buf] + ka) = lo;
+        split4(vreg[i], hi, lo);
+        // V: [16-d tile][key][16 d] (32-byte rows) for the transposed reads
+        const size_t va = (size_t)(dc >> 1) * (KB * 32) + key * 32 + (dc & 1) * 16 + half;
+        *(u32x2*)(vhi[buf] + va) = hi;
+        *(u32x2*)(vlo[buf] + va) = lo;
+      }
+    }
+  };
+
+  load_block(0);
+  // Q^T fragments of this wave's head (B operand: column = query), hi and lo
+  u32x4 qh[KK], ql[KK];
+  const int tq = min(t0 + c16, s.L - 1);              // this lane's query (clamped; stores are guarded)
+  {
+    const float* qp = (const float*)c.q + ((size_t)b * s.L + tq) * s.Hq * D + (size_t)h * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const f32x4 a = *(const f32x4*)(qp + 32 * kk + 8 * g4), bq = *(const f32x4*)(qp + 32 * kk + 8 * g4 + 4);
+      u32x2 h0, l0, h1, l1;
+      split4(a, h0, l0);
+      split4(bq, h1, l1);
+      qh[kk] = u32x4{h0.x, h0.y, h1.x, h1.y};
+      ql[kk] = u32x4{l0.x, l0.y, l1.x, l1.y};
+    }
+  }
+  store_block(0);
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) asm volatile("" :: "v"(qh[kk]), "v"(ql[kk]));     // (see attn_prefill_kernel: the Q loads are complete from here on)
+  __syncthreads();
+
+  const float sc2 = c.scale * LOG2E;
+  const int qpos = off + t0 + c16;                    // key positions <= qpos are visible to this lane's query
+  float m_run = -1e30f, l_run = 0.f;
+  f32x4 accO[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) accO[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tq4 = c16 >> 2, tp = c16 & 3;
+
+  for (int j = 0; j < nb; ++j) {
+    const int buf = j & 1;
+    load_block(j + 1);                                // straight-line (past the last block: clamped keys, never stored); the loads fly during this block's work
+    f32x4 sc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const size_t fa = (size_t)(((t * KK + kk) * 4 + g4) * 16 + c16) * 16;
+        const u32x4 kfh = *(const u32x4*)(khi[buf] + fa);
+        const u32x4 kfl = *(const u32x4*)(klo[buf] + fa);
+        sc[t] = mfma16<T>(kfh, qh[kk], sc[t]);
+        sc[t] = mfma16<T>(kfh, ql[kk], sc[t]);
+        sc[t] = mfma16<T>(kfl, qh[kk], sc[t]);
+      }
+    }
+    float mx = -INFINITY;
+    if (j * KB + KB - 1 > off + t0) {                 // a diagonal block (uniform)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (j * KB + 16 * t + 4 * g4 + r) <= qpos;
+          sc[t][r] = ok ? sc[t][r] : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m_run, mx * sc2);          // (scale > 0: the largest raw score is the largest scaled one)
+    if (__builtin_amdgcn_ballot_w64(mn != m_run) != 0) {
+      const float corr = __builtin_amdgcn_exp2f(m_run - mn);
+      m_run = mn;
+      l_run *= corr;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) accO[dt] *= corr;
+    }
+    float p[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], sc2, -mn)); l_run += p[t][r]; }
+    uint32_t ph[4], pw[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      pack2_split<T>(p[t][0], p[t][1], ph[2 * t], pw[2 * t]);
+      pack2_split<T>(p[t][2], p[t][3], ph[2 * t + 1], pw[2 * t + 1]);
+    }
+    const u32x4 pf = {ph[0], ph[1], ph[2], ph[3]}, pl = {pw[0], pw[1], pw[2], pw[3]};
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const size_t va = (size_t)dt * (KB * 32) + (4 * g4 + tq4) * 32 + tp * 8;
+      const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vhi[buf] + va));
+      const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vhi[buf] + va + 16 * 32));
+      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vlo[buf] + va));
+      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vlo[buf] + va + 16 * 32));
+      const u32x4 vfh = {((const uint32_t*)&h0)[0], ((const uint32_t*)&h0)[1], ((const uint32_t*)&h1)[0], ((const uint32_t*)&h1)[1]};
+      const u32x4 vfl = {((const uint32_t*)&l0)[0], ((const uint32_t*)&l0)[1], ((const uint32_t*)&l1)[0], ((const uint32_t*)&l1)[1]};
+      accO[dt] = mfma16<T>(vfh, pf, accO[dt]);
+      accO[dt] = mfma16<T>(vfh, pl, accO[dt]);
+      accO[dt] = mfma16<T>(vfl, pf, accO[dt]);
+    }
+    if (j + 1 < nb) store_block(buf ^ 1);             // the other buffer: nobody reads it during this block
+    __syncthreads();
+  }
+
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (t0 + c16 < s.L) {
+    const float inv = 1.0f / l_run;
+    float* op = (float*)c.out + ((size_t)b * s.L + tq) * s.Hq * D + (size_t)h * D + 4 * g4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x4 v = {round_rt(accO[dt][0] * inv, s.rnd), round_rt(accO[dt][1] * inv, s.rnd),
+                       round_rt(accO[dt][2] * inv, s.rnd), round_rt(accO[dt][3] * inv, s.rnd)};
+      *(f32x4*)(op + 16 * dt) = v;
+    }
+  }
+}
+
 template <int D, int G>
 int launch_pg32(const AttnCall& c, hipStream_t st) {
   const AttnShape& s = c.s;
   const dim3 grid((s.L + QT - 1) / QT, s.B * s.Hkv), block(G * 64);
-  if (s.btab) hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G, true>), grid, block, 0, st, c);
+  const char* env = getenv("MI_ATTN_PREFILL_F32_EXACT");   // A/B and the comparison test (read per call): 1 = exact float32 products
+  if (env == nullptr || atoi(env) == 0) {
+    if (s.btab) hipLaunchKernelGGL((attn_prefill_f32s_kernel<D, G, true>), grid, block, 0, st, c);
+    else hipLaunchKernelGGL((attn_prefill_f32s_kernel<D, G, false>), grid, block, 0, st, c);
+  } else if (s.btab) hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G, true>), grid, block, 0, st, c);
   else hipLaunchKernelGGL((attn_prefill_f32_kernel<D, G, false>), grid, block, 0, st, c);
   MI_HIP(hipGetLastError());
   return MI_OK;

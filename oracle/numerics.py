@@ -77,8 +77,15 @@ X_SPLIT2 = False
 
 
 def set_x_split2(on: bool) -> None:
-    global X_SPLIT2
+    global X_SPLIT2, SDPA_SPLIT2
     X_SPLIT2 = bool(on)
+    SDPA_SPLIT2 = bool(on)
+
+
+# ... and with it the float32 PREFILL attention (more than one query position) on two-term operands: q, K, P and V each as
+# hi + lo of bfloat16 (what three matrix-core products per pair -- hi.hi + hi.lo + lo.hi -- see; the lo.lo product, 2^-16
+# relative, is not modelled separately: rounding each operand to 16+ bits is the larger effect)
+SDPA_SPLIT2 = False
 
 
 def split2(x: np.ndarray, dtype: str) -> np.ndarray:

@@ -262,7 +262,10 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     odt = promote(qdt, kdt)
     if numerics.ACCUM != "exact":
         p16 = kdt if (numerics.SDPA_P16 and kdt != "float32") else None
-        return round_to(_sdpa_f32(q, k, v, scale, mask, numerics.ACCUM, p16), odt), odt
+        s2 = numerics.SDPA_SPLIT2 and L > 1 and odt == "float32"
+        if s2:
+            q, k, v = (numerics.split2(a, "bfloat16") for a in (q, k, v))
+        return round_to(_sdpa_f32(q, k, v, scale, mask, numerics.ACCUM, p16, s2), odt), odt
     k = np.repeat(k, rep, axis=1).astype(np.float64)
     v = np.repeat(v, rep, axis=1).astype(np.float64)
     s = np.matmul(q.astype(np.float64), k.transpose(0, 1, 3, 2)) * float(scale)     # (B,H,L,S), float64 sums
@@ -275,7 +278,7 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     return round_to(o, odt), odt
 
 
-def _sdpa_f32(q, k, v, scale, mask, mode, p16=None):
+def _sdpa_f32(q, k, v, scale, mask, mode, p16=None, p_split2=False):
     """The same attention with float32 accumulators (accumulation envelope, numerics.set_accum): scores = chunks of 32
     head-dim products, softmax in float32 (max, exp, sum over chunks of 32 keys), P.V over chunks of 32 keys; per
     (row, kv head) to bound memory.  Output float32 values, rounded to the output dtype by the caller."""
@@ -299,6 +302,8 @@ def _sdpa_f32(q, k, v, scale, mask, mode, p16=None):
             den = numerics.sum_last_f32(p, mode)[..., None]
             if p16 is not None:                                            # numerics.SDPA_P16: 16-bit P operands, float32 sum
                 p = round_to(p, p16)
+            if p_split2:                                                   # numerics.SDPA_SPLIT2: P as hi + lo
+                p = numerics.split2(p, "bfloat16")
             a = numerics.Accum(mode)
             for s0 in range(0, S, CH):
                 a.add(np.matmul(p[..., s0:s0 + CH].astype(np.float64), vv[s0:s0 + CH].astype(np.float64)).astype(np.float32))

@@ -309,6 +309,27 @@ def test_prefill_attention_many_blocks(act, Hq, Hkv, D):
         outs[mode] = out
     assert torch.equal(outs["1"], outs["0"]), "LDS-DMA prefill attention differs from the register-staged kernel"
     got = host(outs["1"]).reshape(B, L_, Hq, D)
+    if act == "float32":
+        # float32 caches: the default kernel multiplies two-term bf16 splits of q, K, P and V on the bf16 matrix core (three
+        # MFMAs per product, 16+ mantissa bits per operand); MI_ATTN_PREFILL_F32_EXACT=1 is the exact-product kernel on
+        # v_mfma_f32_16x16x4_f32.  The two must agree to the dropped lo.lo terms (2^-16 of a product) ...
+        exact = torch.zeros_like(outs["1"])
+        os.environ["MI_ATTN_PREFILL_F32_EXACT"] = "1"
+        try:
+            L.check(L.lib().mi_op_attention(C.byref(s), ptr(q_d), ptr(kc_d), ptr(vc_d), ptr(off_d), ptr(exact),
+                                            float(D ** -0.5), 1, ptr(part)))
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["MI_ATTN_PREFILL_F32_EXACT"]
+        d = (outs["1"] - exact).abs()
+        assert 0.0 < float(d.max()) <= 2e-5 and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))
+        # ... and the exact kernel holds a 10 x tighter bound against the oracle than the common one below
+        ge = host(exact).reshape(B, L_, Hq, D)
+        for b in range(B):
+            for t in (0, 16, 77, L_ - 1):
+                n = offs[b] + t + 1
+                o, _ = ref_model.sdpa(q[b:b + 1, t:t + 1].transpose(0, 2, 1, 3), kc[b:b + 1, :, :n], vc[b:b + 1, :, :n], D ** -0.5, None, act, act)
+                assert np.allclose(ge[b, t], o[0, :, 0], rtol=1e-5, atol=2e-6), (b, t, np.abs(ge[b, t] - o[0, :, 0]).max())
     for b in range(B):
         for t in (0, 1, 15, 16, 31, 32, 77, L_ - 1):
             n = offs[b] + t + 1
