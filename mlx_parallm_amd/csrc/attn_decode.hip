@@ -398,6 +398,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecodeCall c) {
 //     lane scalar.  Waves, the new key and the splits are merged as in the VALU kernel.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 
@@ -430,13 +431,15 @@ __device__ __forceinline__ void pack2_split(float a, float b, uint32_t& hi, uint
 }
 
 template <int G, int D, int ES = 2, int NWV = 8>
-__host__ __device__ constexpr size_t attn_mfma_vimg_bytes() { return ES == 2 ? (size_t)NWV * 32 * D * 2 : 0; }   // float32 caches: no V image
+__host__ __device__ constexpr size_t attn_mfma_vimg_bytes() {     // float32 caches, exact products (ES 4): no V image; split operands (ES 8): a hi and a lo image per wave
+  return ES == 2 ? (size_t)NWV * 32 * D * 2 : ES == 8 ? (size_t)NWV * 32 * D * 4 : 0;
+}
 
 template <int G, int D, int ES = 2, int NWV = 8>
 __host__ __device__ constexpr size_t attn_mfma_lds_bytes() {
   // [V images: NWV waves x 32 keys x D x 2 B (16-bit caches only)][q + new key: (G + 1) x D x ES B]
   // [st_o: (NWV + 1) x G x D floats][st_m, st_l: (NWV + 1) x G floats each]
-  return attn_mfma_vimg_bytes<G, D, ES, NWV>() + (size_t)(G + 1) * D * ES + (size_t)(NWV + 1) * G * D * 4 + (size_t)2 * (NWV + 1) * G * 4 + 16;
+  return attn_mfma_vimg_bytes<G, D, ES, NWV>() + (size_t)(G + 1) * D * (ES == 8 ? 4 : ES) + (size_t)(NWV + 1) * G * D * 4 + (size_t)2 * (NWV + 1) * G * 4 + 16;
 }
 
 // float32 caches (the PagedKVCache mode, base.py:104-140): v_mfma_f32_16x16x4_f32 -- exact float32 products, one float per
@@ -479,12 +482,23 @@ __device__ __forceinline__ void store_out(T* p, T v, bool write_through) {
 // 2257 tok/s, float32 caches 1928 vs 1962: the extra round of eight waves costs less than four more waves' prologue,
 // LDS merge (13 slots) and the third wave per SIMD.  Kept behind -DMI_ATTN_WIDE (compile-time: it doubles this file's
 // instantiations), not built by default.
-template <typename T, int D, int G, bool NORM, bool WT, bool PAGED, int NWV, class Hook>
+// SPLIT (float32 caches only, round 4; -DMI_ATTN_DECODE_SPLIT_BUILD): q, K, P and V as two bf16 terms each (hi + lo, 16+ mantissa
+// bits) and every product as three v_mfma_f32_16x16x32_bf16 (hi.hi + hi.lo + lo.hi) in the 16-bit kernel's layouts -- 32
+// keys per wave and round (a 1024-key context in ONE round of four splits, where the exact float32 form below needs two) and
+// a fifth of the matrix-core cycles of v_mfma_f32_16x16x4_f32.  K fragments are split in registers, V rows while they are
+// written to the wave's two LDS images.  Measured SLOWER than the exact form (launch_mfma_g has the numbers): not
+// instantiated by default.  (The same idea pays in the PREFILL attention, where the matrix core is the bound.)
+template <typename T, int D, int G, bool NORM, bool WT, bool PAGED, int NWV, bool SPLIT, class Hook>
 __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, unsigned char* smem, Hook after_loads) {
-  constexpr bool F32 = sizeof(T) == 4;
+  constexpr bool T32 = sizeof(T) == 4;           // float32 q / caches / outputs
+  constexpr bool F32 = T32 && !SPLIT;            // ... multiplied exactly on v_mfma_f32_16x16x4_f32
+  constexpr bool F32S = T32 && SPLIT;            // ... or as two-term bf16 splits on v_mfma_f32_16x16x32_bf16
+  static_assert(!SPLIT || T32, "SPLIT is a mode of the float32 caches");
+  constexpr int ESL = F32S ? 8 : (int)sizeof(T); // the LDS layout's element-size code (attn_mfma_lds_bytes)
   static_assert(D % 32 == 0 && D <= 128 && G <= 8 && (!F32 || D % 64 == 0), "16-bit caches: head_dim 32/64/96/128; float32: 64/128");
   constexpr int EPL = D / 16, NW32 = EPL * (int)sizeof(T) / 4, NTH = NWV * 64;
   constexpr int KK = D / 32, DT = D / 16, NV = (32 * D * 2) / (64 * 16);   // K steps, 16-d tiles, 16-B V loads per lane
+  constexpr int NVS = (32 * D * 4) / (64 * 16);  // F32S: 16-B (4-float) V loads per lane and round
   constexpr int KPW = F32 ? 16 : 32;             // keys per wave and round
   constexpr int NP = D / 16, NH = D / 64 > 0 ? D / 64 : 1;   // float32: 16-byte K pieces per lane and tile, 64-d halves of a V row
   constexpr float LOG2E = 1.4426950408889634f;
@@ -506,8 +520,8 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   const int nq = s.Hq * D;
   const T* row = (const T*)c.qkv + (size_t)b * (nq + 2 * s.Hkv * D);
 
-  constexpr size_t VIMG = attn_mfma_vimg_bytes<G, D, (int)sizeof(T), NWV>();
-  unsigned char* vimg = smem + (size_t)wave * (32 * D * 2);          // this wave's V image (16-bit caches)
+  constexpr size_t VIMG = attn_mfma_vimg_bytes<G, D, ESL, NWV>();
+  unsigned char* vimg = smem + (size_t)wave * (32 * D * 2) * (F32S ? 2 : 1);   // this wave's V image (16-bit caches; F32S: hi image, lo image behind it)
   T* q_sh = (T*)(smem + VIMG);                                        // [G + 1][D]: q heads, then the new key
   float* st_o = (float*)(smem + VIMG + (size_t)(G + 1) * D * sizeof(T));   // [NWV + 1][G][D]
   float* st_m = st_o + (NWV + 1) * G * D;                             // [NWV + 1][G]
@@ -519,8 +533,9 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   const int send = min(s0 + chunk, pos);         // cached keys of this split: [s0, send)
 
   // ---- the K fragments and V rows of the first round go out before anything else
-  u32x4 kf[F32 ? 1 : 2][F32 ? 1 : KK], vrow[F32 ? 1 : NV];
+  u32x4 kf[T32 ? 1 : 2][T32 ? 1 : KK], vrow[T32 ? 1 : NV];
   f32x4 kf32[F32 ? NP : 1], vv32[F32 ? 4 : 1][F32 ? NH : 1];
+  f32x4 kraw[F32S ? 2 : 1][F32S ? KK : 1][2], vraw[F32S ? NVS : 1];   // F32S: the float32 bits of the 16-bit kernel's fragments / rows
   const int klast = max(send - 1, 0);            // every address is clamped to a valid row: no load sits under a branch
   auto issue_k = [&](int base) {                 // keys base + KPW wave + [0, KPW)
     const int k0 = base + KPW * wave;
@@ -529,6 +544,17 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
       const size_t ro = kv_elem<PAGED>(s, kb, kh, key);
 #pragma unroll
       for (int i = 0; i < NP; ++i) kf32[i] = *(const f32x4*)(kc + ro + 16 * i + 4 * g4);
+    } else if constexpr (F32S) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int key = min(k0 + 16 * t + c16, klast);
+        const size_t ro = kv_elem<PAGED>(s, kb, kh, key);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          kraw[t][kk][0] = *(const f32x4*)(kc + ro + 32 * kk + 8 * g4);
+          kraw[t][kk][1] = *(const f32x4*)(kc + ro + 32 * kk + 8 * g4 + 4);
+        }
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -548,6 +574,13 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
         const size_t ro = kv_elem<PAGED>(s, kb, kh, key);
 #pragma unroll
         for (int h = 0; h < NH; ++h) vv32[r][h] = *(const f32x4*)(vc + ro + 64 * h + 4 * c16);
+      }
+    } else if constexpr (F32S) {                 // 32 keys x (D/4) 16-byte pieces of 4 floats, lane-linear
+#pragma unroll
+      for (int i = 0; i < NVS; ++i) {
+        const int piece = i * 64 + lane, kl = piece / (D / 4), dc4 = piece % (D / 4);
+        const int key = min(k0 + kl, klast);
+        vraw[i] = *(const f32x4*)(vc + kv_elem<PAGED>(s, kb, kh, key) + 4 * dc4);
       }
     } else {                                     // 32 keys x (D/8) 16-byte pieces, lane-linear: piece = i * 64 + lane
 #pragma unroll
@@ -605,7 +638,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     x[e] = to_f32(store_act<T>(o, s.rnd));
   }
   uint32_t pk[NW32];
-  if constexpr (F32) {
+  if constexpr (T32) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) pk[e] = is_v ? raw[e] : __float_as_uint(x[e]);
   } else {
@@ -639,7 +672,7 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
     for (int j = 0; j < (G + 3) / 4; ++j) {
       const int g = min(gq + 4 * j, G - 1);
       float d = 0.f;
-      if constexpr (F32) {
+      if constexpr (T32) {
 #pragma unroll
         for (int i = 0; i < NW32; ++i)
           d = fmaf(__uint_as_float(kn[i]), __uint_as_float(((const uint32_t*)(q_sh + (size_t)g * D + li * EPL))[i]), d);
@@ -651,9 +684,27 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
       if (li == 0 && gq + 4 * j < G) { st_m[NWV * G + g] = owner ? d : -1e30f; st_l[NWV * G + g] = owner ? 1.f : 0.f; }
     }
   }
-  u32x4 qf[F32 ? 1 : KK];
+  u32x4 qf[T32 ? 1 : KK];
+  u32x4 qh[F32S ? KK : 1], ql[F32S ? KK : 1];
   f32x4 qf32[F32 ? NP : 1];
-  if constexpr (F32) {
+  auto split8 = [](const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {     // 8 floats -> 8 bf16 hi + 8 bf16 lo
+    uint32_t h[4], l[4];
+    pack2_split<bf16>(a.x, a.y, h[0], l[0]);
+    pack2_split<bf16>(a.z, a.w, h[1], l[1]);
+    pack2_split<bf16>(b.x, b.y, h[2], l[2]);
+    pack2_split<bf16>(b.z, b.w, h[3], l[3]);
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+  };
+  if constexpr (F32S) {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const float* qp = (const float*)q_sh + (size_t)(c16 < G ? c16 : 0) * D + 32 * kk + 8 * g4;
+      f32x4 a = *(const f32x4*)qp, bq = *(const f32x4*)(qp + 4);
+      if (c16 >= G) { a = f32x4{0.f, 0.f, 0.f, 0.f}; bq = a; }
+      split8(a, bq, qh[kk], ql[kk]);
+    }
+  } else if constexpr (F32) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       qf32[i] = *(const f32x4*)(q_sh + (size_t)(c16 < G ? c16 : 0) * D + 16 * i + 4 * g4);
@@ -710,6 +761,84 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
       __builtin_amdgcn_sched_barrier(0);
       issue_v(base + KPW * NWV);                 // ... and the next round's V rows
       __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (F32S) {
+    for (int base = s0; base < send; base += 32 * NWV) {      // uniform trip count; 32 keys per wave and round
+      f32x4 sc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          u32x4 kfh, kfl;
+          split8(kraw[t][kk][0], kraw[t][kk][1], kfh, kfl);
+          sc[t] = mfma_kq<bf16>(kfh, qh[kk], sc[t]);
+          sc[t] = mfma_kq<bf16>(kfh, ql[kk], sc[t]);
+          sc[t] = mfma_kq<bf16>(kfl, qh[kk], sc[t]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      issue_k(base + 32 * NWV);                  // rolling prefetch: the next round's K into the registers just consumed
+      __builtin_amdgcn_sched_barrier(0);
+      const int k0 = base + 32 * wave;
+      float mx = -1e30f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (k0 + 16 * t + 4 * g4 + r) < send;
+          sc[t][r] = ok ? sc[t][r] * sc2 : -INFINITY;
+          mx = fmaxf(mx, sc[t][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));    // max over the wave's 32 keys, per head
+      const float mn = fmaxf(m_run, mx);
+      const float corr = __builtin_amdgcn_exp2f(m_run - mn);
+      m_run = mn;
+      l_run *= corr;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) accO[dt] *= corr;
+      float p[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - mn); l_run += p[t][r]; }
+      uint32_t ph[4], pw[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        pack2_split<bf16>(p[t][0], p[t][1], ph[2 * t], pw[2 * t]);
+        pack2_split<bf16>(p[t][2], p[t][3], ph[2 * t + 1], pw[2 * t + 1]);
+      }
+      const u32x4 pf = {ph[0], ph[1], ph[2], ph[3]}, pl = {pw[0], pw[1], pw[2], pw[3]};
+      // V rows -> hi / lo -> this wave's two images [16-d tile][key][16 d]
+      unsigned char* vlo = vimg + 32 * D * 2;
+#pragma unroll
+      for (int i = 0; i < NVS; ++i) {
+        const int piece = i * 64 + lane, kl = piece / (D / 4), dc4 = piece % (D / 4), dc = dc4 >> 1;
+        const size_t va = (size_t)(dc >> 1) * 1024 + kl * 32 + (dc & 1) * 16 + (dc4 & 1) * 8;
+        uint32_t h0, l0, h1, l1;
+        pack2_split<bf16>(vraw[i].x, vraw[i].y, h0, l0);
+        pack2_split<bf16>(vraw[i].z, vraw[i].w, h1, l1);
+        *(u32x2v*)(vimg + va) = u32x2v{h0, h1};
+        *(u32x2v*)(vlo + va) = u32x2v{l0, l1};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      issue_v(base + 32 * NWV);                  // ... and the next round's V rows
+      __builtin_amdgcn_sched_barrier(0);
+      const int tq = c16 >> 2, tp = c16 & 3;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const size_t a0 = (size_t)dt * 1024 + (4 * g4 + tq) * 32 + tp * 8;
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vimg + a0));
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vimg + a0 + 16 * 32));
+        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vlo + a0));
+        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vlo + a0 + 16 * 32));
+        const u32x4 vfh = {((const uint32_t*)&h0)[0], ((const uint32_t*)&h0)[1], ((const uint32_t*)&h1)[0], ((const uint32_t*)&h1)[1]};
+        const u32x4 vfl = {((const uint32_t*)&l0)[0], ((const uint32_t*)&l0)[1], ((const uint32_t*)&l1)[0], ((const uint32_t*)&l1)[1]};
+        accO[dt] = mfma_kq<bf16>(vfh, pf, accO[dt]);
+        accO[dt] = mfma_kq<bf16>(vfh, pl, accO[dt]);
+        accO[dt] = mfma_kq<bf16>(vfl, pf, accO[dt]);
+      }
     }
   } else {
   for (int base = s0; base < send; base += 32 * NWV) {        // uniform trip count
@@ -839,10 +968,10 @@ __device__ __forceinline__ void attn_decode_mfma_body(const AttnDecodeCall& c, u
   }
 }
 
-template <typename T, int D, int G, bool NORM, bool PAGED, int NWV>
+template <typename T, int D, int G, bool NORM, bool PAGED, int NWV, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64) void attn_decode_mfma_kernel(AttnDecodeCall c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  attn_decode_mfma_body<T, D, G, NORM, false, PAGED, NWV>(c, smem, NoHook{});
+  attn_decode_mfma_body<T, D, G, NORM, false, PAGED, NWV, SPLIT>(c, smem, NoHook{});
 }
 
 template <typename T, int D, int G, bool NORM>
@@ -872,7 +1001,31 @@ int launch_mfma_g(const AttnDecodeCall& c, hipStream_t st) {
   else { if (wide) LAUNCH_MFMA(false, 12); else LAUNCH_MFMA(false, 8); }
 #else
   (void)wide; (void)KPW;
-  if (s.btab) LAUNCH_MFMA(true, 8); else LAUNCH_MFMA(false, 8);
+#ifdef MI_ATTN_DECODE_SPLIT_BUILD
+  if constexpr (sizeof(T) == 4) {
+    // float32 caches on two-term bf16 operands (SPLIT): BUILT, oracle-tested (test_fused_decode_attention ran it as variant
+    // 0) and MEASURED SLOWER than the exact float32 form on the bench -- 1913 / 1907 against 1998 / 1987 tok/s, same box,
+    // alternating: at 8 x 1024 keys the exact kernel's matrix-core time is ~3.4 us of its 19.7 and what the split saves there
+    // it spends converting K and V (2 x 64 floats per lane and round) and on the two LDS images.  Compiled only with
+    // -DMI_ATTN_DECODE_SPLIT_BUILD (it doubles the float32 instantiations); then MI_ATTN_DECODE_F32_SPLIT=1 selects it.
+    const char* env = getenv("MI_ATTN_DECODE_F32_SPLIT");
+    constexpr bool fits = attn_mfma_lds_bytes<G, D, 8, 8>() <= (size_t)160 * 1024;   // (G = 8 at D = 128 does not fit the LDS)
+    const bool split = fits && c.variant != 3 && env != nullptr && atoi(env) != 0;
+#define LAUNCH_MFMA_S(PG) do { \
+    auto kern = attn_decode_mfma_kernel<T, D, G, NORM, PG, 8, true>; \
+    constexpr size_t lds = attn_mfma_lds_bytes<G, D, 8, 8>(); \
+    MI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, grid, dim3(8 * 64), lds, st, c); } while (0)
+    if constexpr (fits) {
+      if (split) { if (s.btab) LAUNCH_MFMA_S(true); else LAUNCH_MFMA_S(false); }
+    }
+    if (!split) { if (s.btab) LAUNCH_MFMA(true, 8); else LAUNCH_MFMA(false, 8); }
+#undef LAUNCH_MFMA_S
+  } else
+#endif
+  {
+    if (s.btab) LAUNCH_MFMA(true, 8); else LAUNCH_MFMA(false, 8);
+  }
 #endif
 #undef LAUNCH_MFMA
   MI_HIP(hipGetLastError());

@@ -86,6 +86,7 @@ def set_x_split2(on: bool) -> None:
 # hi + lo of bfloat16 (what three matrix-core products per pair -- hi.hi + hi.lo + lo.hi -- see; the lo.lo product, 2^-16
 # relative, is not modelled separately: rounding each operand to 16+ bits is the larger effect)
 SDPA_SPLIT2 = False
+SDPA_SPLIT2_DECODE = False     # ... the decode steps' attention too (an experiment: the device's split decode form lost on speed)
 
 
 def split2(x: np.ndarray, dtype: str) -> np.ndarray:

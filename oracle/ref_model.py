@@ -262,7 +262,7 @@ def sdpa(q, k, v, scale: float, mask: Optional[np.ndarray], qdt: str, kdt: str):
     odt = promote(qdt, kdt)
     if numerics.ACCUM != "exact":
         p16 = kdt if (numerics.SDPA_P16 and kdt != "float32") else None
-        s2 = numerics.SDPA_SPLIT2 and L > 1 and odt == "float32"
+        s2 = numerics.SDPA_SPLIT2 and (L > 1 or numerics.SDPA_SPLIT2_DECODE) and odt == "float32"
         if s2:
             q, k, v = (numerics.split2(a, "bfloat16") for a in (q, k, v))
         return round_to(_sdpa_f32(q, k, v, scale, mask, numerics.ACCUM, p16, s2), odt), odt

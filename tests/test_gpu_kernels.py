@@ -347,7 +347,9 @@ def test_fused_decode_attention(act, Hq, Hkv, D, qk_norm, variant):
     """mi_op_attention_decode: q/k norm + RoPE + KV append + attention + split combine in one launch,
     MFMA (variant 0, 16-bit caches) and VALU (variant 1) kernels: ragged per-row context lengths up to
     eight 256-key rounds, 1 / 3 / 4 / 8 splits; the cache must receive exactly the new K / V row."""
-    # (float32 caches: variant 0 is the v_mfma_f32_16x16x4_f32 kernel for head_dim 64 / 128, the VALU kernel otherwise)
+    # (float32 caches: variant 0 is the v_mfma_f32_16x16x4_f32 kernel for head_dim 64 / 128 -- exact float32 products, held to
+    # a 10 x tighter bound below -- and the VALU kernel otherwise.  A form on two-term bf16 operands was built, passed this
+    # test as variant 0 and measured slower: attn_decode.hip, -DMI_ATTN_DECODE_SPLIT_BUILD.)
     # 1023 / 1024 / 1100: the bench's regime (one full 4 x 256-key pass, then a second, nearly empty round per
     # workgroup); 2047: eight rounds
     B, cap, max_pos = 8, 2064, 2112
@@ -393,7 +395,9 @@ def test_fused_decode_attention(act, Hq, Hkv, D, qk_norm, variant):
         assert np.array_equal(host(vc_d), vc_ref)
         assert not ctr.cpu().numpy().any()                 # tickets are handed back for the next launch
         got = host(out)
-        if act == "float32":
+        if act == "float32" and variant == 0 and D % 64 == 0:
+            assert np.allclose(got, want, rtol=1e-5, atol=2e-6), np.abs(got - want).max()
+        elif act == "float32":
             assert np.allclose(got, want, rtol=1e-4, atol=2e-5), np.abs(got - want).max()
         else:
             assert close_frac(got, want, act, atol=2e-3) <= 0.02, (nsplit, close_frac(got, want, act, atol=2e-3))
