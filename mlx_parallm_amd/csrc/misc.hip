@@ -114,7 +114,9 @@ int launch_embed_wk(const LinearW& W, const EmbedCall& c, hipStream_t st) {
 constexpr int ST = 1024;
 
 // f(value, index) over one row of logits.  A pass is latency-bound if every thread walks it one dependent 4-byte load
-// at a time (measured: ~9 us per pass over 32000 logits); 16-byte loads, two in flight per thread.
+// at a time (measured: ~9 us per pass over 32000 logits); 16-byte loads, two in flight per thread.  (Four in flight:
+// measured in round 4, no change -- 55.7 us per top-p draw at V = 32000 either way.  What bounds the histogram passes is
+// the same-address serialisation of their LDS atomics: a row's logits share a handful of exponents.)
 template <class F>
 __device__ __forceinline__ void for_row(const float* lg, int V, F f) {
   if ((V & 3) == 0 && (((uintptr_t)lg) & 15) == 0) {
@@ -473,9 +475,12 @@ __global__ __launch_bounds__(ST) void sample_kernel(SampleCall c) {
   float lp_scale = 1.0f, lp_lse = lse - mx;
   if (c.lp_temp && temperature > 0.f) {
     lp_scale = 1.0f / temperature;
-    float st = 0.f;
-    for_row(lg, V, [&](float l, int) { st += __expf((l - mx) * lp_scale); });
-    st = block_sum(st, sh_f);
+    float st = se;                               // T = 1: the sum of the pass above, term for term (no second walk of the row)
+    if (lp_scale != 1.0f) {                      // (uniform)
+      st = 0.f;
+      for_row(lg, V, [&](float l, int) { st += __expf((l - mx) * lp_scale); });
+      st = block_sum(st, sh_f);
+    }
     lp_lse = __logf(st);
   }
   // a row without a single comparable logit (all NaN / -inf: a broken checkpoint, an overflow upstream) has no
