@@ -171,8 +171,13 @@ def test_device_matches_oracle_at_production_width(checkpoints, path):
             ids8, vals8 = g["top_ids"][s, b], g["top_vals"][s, b]
             if gt != wt:
                 near += 1
-                if greedy:
+                if greedy and layers == wide_models.LAYERS:
                     assert g["margins"][s, b] <= margin_eps and gt in ids8[:3], (path.stem, s, b, gt, wt, float(g["margins"][s, b]))
+                elif greedy:
+                    # full depth: the envelope moves 16-bit logits by up to 0.19, and several candidates can lie that close to the
+                    # top -- the device's pick must be one of the oracle's 8 largest AND within the flip margin of its largest
+                    gap = float(vals8[0] - vals8[list(ids8).index(gt)]) if gt in ids8 else float("inf")
+                    assert g["margins"][s, b] <= margin_eps and gap <= margin_eps, (path.stem, s, b, gt, wt, float(g["margins"][s, b]), gap)
                 elif gt in ids8:               # a different draw that is among the oracle's 8 most likely: its logprob must be the oracle's
                     logz = float(vals8[list(ids8).index(wt)]) - float(g["logprobs"][s, b]) if wt in ids8 else None
                     if logz is not None:

@@ -383,3 +383,48 @@ def test_float32_activations_on_bf16_weights(M, N, K, ksplit, rnd):
         out = torch.zeros((M, I), dtype=torch.float32, device="cuda")
         gemm_skinny(ol, xd, M, "float32", epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, ksplit=1, rnd=0)
         _assert_close(host(out), want, "float32")
+
+
+@pytest.mark.parametrize("act,kind", [("bfloat16", "q4_bf16"), ("float16", "q4_f16")])
+@pytest.mark.parametrize("M", [33, 64, 100, 128])
+def test_q4_default_plan_on_wide_matrices(act, kind, M):
+    """What the engine launches for a decode step of 33..128 sequences on int4 weights, with NO forced plan: the wide
+    matrices (>= 1024 column tiles: gate|up, lm_head) go to gemm_q4.hip under its measured default plan (TW = 5, KW = 2,
+    two staging waves; 4 row tiles per workgroup for SwiGLU, i.e. two row slabs above 64 rows; 2 otherwise), RMSNorm folded
+    into the preparation pass.  Against the oracle; run-to-run identical."""
+    from oracle import ref_model
+
+    eps = 1e-6
+    # SwiGLU over a fused gate|up matrix of 2 x 8192 rows (1024 tiles), RMSNorm in front
+    I, K = 8192, 512
+    ol, wdense, keep = _weight(kind, 2 * I, K, RNG_Q4)
+    x = round_to(RNG_Q4.standard_normal((M, K)).astype(np.float32), act)
+    nw = round_to(1.0 + 0.1 * RNG_Q4.standard_normal(K).astype(np.float32), act)
+    xn = ref_model.rms_norm(x, act, nw, act, eps)[0]
+    g = round_to(matmul_nt(xn, wdense[:I]), act)
+    u = round_to(matmul_nt(xn, wdense[I:]), act)
+    sig = round_to(1.0 / (1.0 + np.exp(-g.astype(np.float64))), act)
+    want = round_to(round_to(g * sig, act) * u, act)
+    xd, nwd = dev(x, act), dev(nw, act)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M + 1, I), 3.0, dtype=xd.dtype, device="cuda")
+        used = gemm_skinny(ol, xd, M, act, epi=L.EPI_SWIGLU, out=out, ldo=I, pair_offset=I, norm_w=nwd, eps=eps)
+        outs.append(host(out))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.all(outs[0][M:] == 3.0)
+    # A million outputs of a chain with TWO independently rounded inputs: g and u may each land one unit off where the
+    # float32 sums of kernel and oracle straddle a rounding boundary (that is _assert_close's 2-unit bound for ONE rounded
+    # sum), each moves silu(g) * u by one unit of the result, and the two roundings behind them (g * sig, then * u) can
+    # turn that into one more half each: every element within 3 units, 90 % within half a unit.  Measured: 2.27 at worst.
+    got = outs[0][:M]
+    unit = {"bfloat16": 2.0 ** -7, "float16": 2.0 ** -10}[act] * np.maximum(np.abs(want), float(np.sqrt(np.mean(np.square(g * u)))))
+    err = np.abs(got - want)
+    assert np.all(err <= 3 * unit), float((err / unit).max())
+    assert np.mean(err > 0.5 * unit) <= 0.10, float(np.mean(err > 0.5 * unit))
+    # float32 logits over an odd number of tiles (1025), no norm
+    N = 16400
+    ol, wdense, keep = _weight(kind, N, K, RNG_Q4)
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    gemm_skinny(ol, xd, M, act, epi=L.EPI_STORE_F32, out=out, ldo=N)
+    _assert_close(host(out), round_to(matmul_nt(x, wdense), act), act)
