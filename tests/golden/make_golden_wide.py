@@ -16,6 +16,12 @@ per case in tests/golden/envelope/<case>.npz: the variants' logprobs of the orac
 logits, their arg-max ids, and a JSON summary (max / mean |logprob - exact|, seq32-vs-pairwise, id flips).  No HIP
 kernel is involved in these numbers: they are what summation order alone does to this model at these widths, and
 tests/test_gpu_golden_wide.py takes its tolerances from them (<= 1.5 x the committed spread).
+Round 4, ADDED to a case's envelope file: `--envelope --p16 <model-KV case>` = the two orders again with the softmax numerators
+rounded to the KV dtype before P.V (keys f32_*_p16: what a 16-bit matrix-core attention with a single P operand computes --
+the rounding that explained the device's round-3 excess); `--envelope --x2 <float32-KV case>` = with the float32
+activations of every call of more than 16 rows and the operands of the prefill attention rounded to two bf16 terms (keys
+f32_*_x2: the arithmetic of the two-term prefill GEMM and the split-operand prefill attention).  Full-depth
+cases (`wide_*_full_*`: all 32 / 40 blocks, 2 x 128-token prompts, 16 steps) run from compact weights (ref_model.COMPACT).
 `--logits` additionally stores the exact oracle's FULL last-position logits of a few (step, row) pairs of the sampled
 case (config 3), against which the test checks the device's inverse-CDF draw.
 
