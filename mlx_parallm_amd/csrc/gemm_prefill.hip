@@ -1010,6 +1010,31 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* x, int ld
     rs = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)K + eps);
   }
   AT* o = out + (size_t)row * terms * K;
+  if ((K & 7) == 0) {                                 // (uniform) 8 elements per thread and trip: 16-byte stores of every term
+    for (int k = tid * 8; k < K; k += 2048) {
+      f32x4 v[2] = {*(const f32x4*)(xr + k), *(const f32x4*)(xr + k + 4)};
+      if (norm_w != nullptr) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 wv = *(const f32x4*)(norm_w + k + 4 * h);
+          v[h].x = (v[h].x * rs) * wv.x; v[h].y = (v[h].y * rs) * wv.y; v[h].z = (v[h].z * rs) * wv.z; v[h].w = (v[h].w * rs) * wv.w;
+        }
+      }
+      AT hi[8], mid[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = v[j >> 2][j & 3];
+        hi[j] = (AT)xv;
+        const float r1 = xv - (float)hi[j];
+        mid[j] = (AT)r1;
+        lo[j] = (AT)(r1 - (float)mid[j]);
+      }
+      *(uint4*)(o + k) = *(const uint4*)hi;
+      *(uint4*)(o + K + k) = *(const uint4*)mid;
+      if (terms == 3) *(uint4*)(o + 2 * K + k) = *(const uint4*)lo;      // (uniform)
+    }
+    return;
+  }
   for (int k = tid * 4; k < K; k += 1024) {
     f32x4 v = *(const f32x4*)(xr + k);
     if (norm_w != nullptr) {
