@@ -232,6 +232,21 @@ def test_greedy_float32_kv_mode_16bit_models(tiny_dirs, name):
     model.engine.close()
 
 
+@pytest.mark.parametrize("B", [33, 100, 128])
+@pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16"])
+def test_decode_steps_of_many_rows_match_oracle(tiny_dirs, name, B):
+    """BASELINE config 5 spreads 128..1024 prompts over the GPUs: decode steps of up to 128 rows per GPU (the split-K
+    streaming kernel in 32-row slabs for int4, two row tiles for 16-bit weights, the decode attention over 128 cache rows;
+    float32 KV: 32-row launches of the float32-activation kernel).  Teacher-forced against the oracle in the reference's
+    numerics: ids equal where the margin allows, logprobs within 1e-3."""
+    model, ref, cfg = _load_pair(tiny_dirs, name)
+    near, total, lp_err = _teacher_forced_greedy(model, ref, cfg, "float32", True, B=B, L0=6, steps=4, margin_eps=2e-3)
+    assert near <= max(1, total // 200) and lp_err <= 1e-3, (near, total, lp_err)
+    near, total, lp_err = _teacher_forced_greedy(model, ref, cfg, "model", False, B=B, L0=6, steps=4, margin_eps=0.13)
+    assert near <= max(2, total // 10) and lp_err <= MODEL_KV_LOGPROB_TOL, (near, total, lp_err)
+    model.engine.close()
+
+
 @pytest.mark.parametrize("name", ["llama_bf16_gqa", "llama_q4_bf16", "qwen3_bf16", "llama_q8_f16", "llama_f16"])
 def test_greedy_model_dtype_kv_16bit_models(tiny_dirs, name):
     """KV and activations in the 16-bit model dtype (the bandwidth-optimal default).  Logits are
