@@ -289,34 +289,45 @@ __global__ __launch_bounds__(Q4_NWMAX * 64, 3) void q4_kernel(const Q4Params p) 
 #pragma unroll
       for (int a = 0; a < TN; ++a) acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sxa[mt], bbv[a], acc[a][mt], 0, 0, 0);
     }
+    // The 2 MT (64-group, row tile) steps as a software pipeline over the x fragments: the two LDS reads of step i + 1 are
+    // issued in front of the MFMAs of step i.  (Two steps ahead spills at 4 row tiles: 168 registers + scratch.)  (Left to itself hipcc emitted "ds_read x 2, s_waitcnt, MFMAs" eight times per
+    // block -- every LDS round trip exposed, with three waves per SIMD to cover it.)
+    auto rd = [&](int idx, u32x4& a0, u32x4& a1) {
+      const int sg = idx / MT, mt = idx % MT;
+      a0 = *(const u32x4*)(buf + frag0 + ((sg * 2 + 0) * MT + mt) * 1024);
+      a1 = *(const u32x4*)(buf + frag0 + ((sg * 2 + 1) * MT + mt) * 1024);
+    };
+    u32x4 c0, c1, n0, n1;
+    rd(0, c0, c1);
+    u32x4 wq[TN][2];
+    float sc[TN];
 #pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      u32x4 wq[TN][2];
-      float sc[TN];
-#pragma unroll
-      for (int a = 0; a < TN; ++a) {
-        wq[a][0] = unpack_q4<AT>(dw[a][sg * 2 + 0]);
-        wq[a][1] = unpack_q4<AT>(dw[a][sg * 2 + 1]);
-        // (integer arithmetic on the whole dword: a type-punned view of an asm load's destination lets the compiler split the
-        // register where it is DEFINED and touch it in front of the wait)
-        if constexpr (std::is_same<AT, bf16>::value) sc[a] = __uint_as_float(sg ? (sr[a][slot] & 0xffff0000u) : (sr[a][slot] << 16));
-        else sc[a] = (float)__builtin_bit_cast(f16, (unsigned short)(sr[a][slot] >> (16 * sg)));
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const u32x4 af0 = *(const u32x4*)(buf + frag0 + ((sg * 2 + 0) * MT + mt) * 1024);
-        const u32x4 af1 = *(const u32x4*)(buf + frag0 + ((sg * 2 + 1) * MT + mt) * 1024);
+    for (int idx = 0; idx < 2 * MT; ++idx) {
+      const int sg = idx / MT, mt = idx % MT;
+      if (idx + 1 < 2 * MT) rd(idx + 1, n0, n1);
+      if (mt == 0) {
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          d = mfma16<AT>(af0, wq[a][0], d);
-          d = mfma16<AT>(af1, wq[a][1], d);
-          acc[a][mt].x = fmaf(sc[a], d.x, acc[a][mt].x);
-          acc[a][mt].y = fmaf(sc[a], d.y, acc[a][mt].y);
-          acc[a][mt].z = fmaf(sc[a], d.z, acc[a][mt].z);
-          acc[a][mt].w = fmaf(sc[a], d.w, acc[a][mt].w);
+          wq[a][0] = unpack_q4<AT>(dw[a][sg * 2 + 0]);
+          wq[a][1] = unpack_q4<AT>(dw[a][sg * 2 + 1]);
+          // (integer arithmetic on the whole dword: a type-punned view of an asm load's destination lets the compiler split the
+          // register where it is DEFINED and touch it in front of the wait)
+          if constexpr (std::is_same<AT, bf16>::value) sc[a] = __uint_as_float(sg ? (sr[a][slot] & 0xffff0000u) : (sr[a][slot] << 16));
+          else sc[a] = (float)__builtin_bit_cast(f16, (unsigned short)(sr[a][slot] >> (16 * sg)));
         }
       }
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = mfma16<AT>(c0, wq[a][0], d);
+        d = mfma16<AT>(c1, wq[a][1], d);
+        acc[a][mt].x = fmaf(sc[a], d.x, acc[a][mt].x);
+        acc[a][mt].y = fmaf(sc[a], d.y, acc[a][mt].y);
+        acc[a][mt].z = fmaf(sc[a], d.z, acc[a][mt].z);
+        acc[a][mt].w = fmaf(sc[a], d.w, acc[a][mt].w);
+      }
+      c0 = n0; c1 = n1;
+      __builtin_amdgcn_sched_barrier(0);
     }
     // The operand registers of the float32 MFMAs stay reserved to the end of the block.  Found on the 16-row instantiation:
     // hipcc re-used them for the unpack right behind the MFMA (a shift into the B operand's register one instruction later)
