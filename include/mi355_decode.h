@@ -243,7 +243,10 @@ int mi_profile_read(mi_engine* e, int64_t* n_launches, double* total_ms);
  * Environment switches read once by the library (A/B runs only): MI_SKINNY_MIN_ROWS (hand-over row count for 16-bit
  * weights, default 9), MI_SKINNY_Q4_MIN_ROWS (set: int4 hands over like 16-bit), MI_SKINNY_NO_F32 (set: float32-KV mode
  * back on the generic VALU kernel), MI_SKINNY_NO_RAGGED_K, MI_GEMM_TILE128 (prefill: always the
- * 128 x 128 tile), MI_GEMM_B_DIRECT (prefill: W fragments straight from global memory). */
+ * 128 x 128 tile), MI_GEMM_B_DIRECT (prefill: W fragments straight from global memory), MI_Q4 (0: int4 decode steps above
+ * 16 rows keep the split-K kernel also on the wide matrices), MI_Q4_NARROW (1: gemm_q4 also for the normed narrow matrix),
+ * MI_ATTN_PREFILL_F32_EXACT (1: float32-KV prefill attention with exact float32 products instead of two-term bf16 operands;
+ * read per call). */
 int mi_engine_set_option(mi_engine* e, const char* key, int64_t value);
 /* Blocks until the engine's stream is idle. */
 int mi_engine_sync(mi_engine* e);
