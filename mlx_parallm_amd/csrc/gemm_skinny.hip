@@ -389,6 +389,65 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
         auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
         dw[a][0] = r0[0]; dw[a][1] = r1[0]; dw[a][2] = r0[1]; dw[a][3] = r1[1];
       }
+      // The 2 MT (64-group, row tile) steps of a unit as a software pipeline over the LDS operands (round 4, as in gemm_q4.hip):
+      // the reads of step j + 1 -- two x fragments and the group sums -- are issued in front of the MFMAs of step j.  Dense
+      // 16-bit activations only (one image); the float32-activation form keeps the plain loop below.
+      // Measured (same box, alternating libraries): <= 16 rows +0.6 % (Mistral-7B int4, B = 8: 3293 / 3285 -> 3313 / 3308 tok/s);
+      // 32-row slabs -0.3 % (config-5 shard 7653 / 7621 -> 7633 / 7599), 6 row tiles spill -- so: the 16-row instantiations only.
+      if constexpr (NIMG == 1 && MT == 1) {
+        auto rd = [&](int idx, u32x4& a0, u32x4& a1, f32x4& sv) {
+          const int sg = idx / MT, mt = idx % MT;
+          const int pb = ((i * 2 + sg) * 2) * 4 * MB + mt * 16;
+          a0 = *(const u32x4*)(cur + lane_off[0] + pb * 16);
+          a1 = *(const u32x4*)(cur + lane_off[1] + (pb + 4 * MB) * 16);
+#ifdef MI_ABL_NOSX
+          sv = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
+          sv = *(const f32x4*)(cur + NIMG * FRAG + ((i * 2 + sg) * MB + mt * 16 + g * 4) * 4);
+#endif
+        };
+        u32x4 c0, c1, n0, n1;
+        f32x4 csx, nsx;
+        rd(0, c0, c1, csx);
+        u32x4 wq[NA][2];
+        float sc[NA], bb[NA];
+#pragma unroll
+        for (int idx = 0; idx < 2 * MT; ++idx) {
+          const int sg = idx / MT, mt = idx % MT;
+          if (idx + 1 < 2 * MT) rd(idx + 1, n0, n1, nsx);
+          if (mt == 0) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+#ifdef MI_ABL_NOUNPACK      // timing-only ablation builds (tools/debug/build_ablation_libs.sh): results are wrong on purpose
+              wq[a][0] = u32x4{dw[a][sg * 2 + 0], dw[a][sg * 2 + 1], dw[a][sg * 2 + 0], dw[a][sg * 2 + 1]};
+              wq[a][1] = u32x4{dw[a][sg * 2 + 1], dw[a][sg * 2 + 0], dw[a][sg * 2 + 1], dw[a][sg * 2 + 0]};
+#else
+              wq[a][0] = unpack_q4<AT>(dw[a][sg * 2 + 0]);
+              wq[a][1] = unpack_q4<AT>(dw[a][sg * 2 + 1]);
+#endif
+              sc[a] = (float)((const AT*)&sr[a][slot])[sg];
+              bb[a] = (float)((const AT*)&br[a][slot])[sg] - Magic<AT>::offs * sc[a];
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+#ifdef MI_ABL_NOFMA
+            acc[a][mt] = mfma16<AT>(c0, wq[a][0], acc[a][mt]);
+            acc[a][mt] = mfma16<AT>(c1, wq[a][1], acc[a][mt]);
+#else
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = mfma16<AT>(c0, wq[a][0], d);
+            d = mfma16<AT>(c1, wq[a][1], d);
+            acc[a][mt].x = fmaf(sc[a], d.x, fmaf(bb[a], csx.x, acc[a][mt].x));
+            acc[a][mt].y = fmaf(sc[a], d.y, fmaf(bb[a], csx.y, acc[a][mt].y));
+            acc[a][mt].z = fmaf(sc[a], d.z, fmaf(bb[a], csx.z, acc[a][mt].z));
+            acc[a][mt].w = fmaf(sc[a], d.w, fmaf(bb[a], csx.w, acc[a][mt].w));
+#endif
+          }
+          c0 = n0; c1 = n1; csx = nsx;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) {
         u32x4 wq[NA][2];
@@ -443,6 +502,7 @@ __global__ __launch_bounds__(SK_NW * 64, (QB == 4 || (QB == 8 && MT >= 3) || MT 
             acc[a][mt].w = fmaf(sc[a], d.w, fmaf(bb[a], sxv.w, acc[a][mt].w));
           }
         }
+      }
       }
     }
   };
